@@ -1,0 +1,173 @@
+/*
+ * gofpid_hip.h -- C ABI of libgofpid_hip.so, the MI355X (gfx950) implementation
+ * of PyGOFPID's per-frame foreground path (steps 1-3 of GOFPID.detect).
+ *
+ * The reference has no FFI of its own: its plug-in surface is Python duck
+ * typing over cv2 calls.  Each entry point below replaces one of those calls
+ * and cites the reference line that makes it; INTEGRATION.md shows the ctypes
+ * binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C, no torch / HIP types in any signature (a stream is passed as
+ *     void*; NULL means the context's own stream).
+ *   - images are dense, C-contiguous uint8: frames (h, w, c) interleaved,
+ *     masks (h, w).  "batch" objects take `streams` such images back to back.
+ *   - every function returns GOF_OK (0) or an error code; gof_last_error()
+ *     gives the message for the calling thread.  GOF_EINVAL is what the Python
+ *     layer turns into ValueError, everything else into RuntimeError.
+ *   - *_host entry points borrow host buffers for the duration of the call and
+ *     are synchronous.  *_dev entry points take device pointers, enqueue on the
+ *     stream and return without synchronising.
+ *   - a context is bound to one device and is NOT thread-safe; distinct
+ *     contexts are independent (the reference runs one GOFPID per video,
+ *     examples/dataset_ilids.py:126-140).
+ */
+#ifndef GOFPID_HIP_H
+#define GOFPID_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GOF_ABI_VERSION 1
+
+enum {
+    GOF_OK = 0,
+    GOF_EINVAL = 1,   /* bad shape / parameter           -> ValueError   */
+    GOF_EHIP = 2,     /* a HIP runtime call failed       -> RuntimeError */
+    GOF_ENOMEM = 3,   /* device or host allocation failed                */
+    GOF_ENODEV = 4    /* no usable gfx950 device                         */
+};
+
+enum { GOF_ERODE = 0, GOF_DILATE = 1 };
+enum { GOF_DET_MOG2 = 0, GOF_DET_FD = 1 };
+enum { GOF_BLUR_NONE = 0, GOF_BLUR_GAUSS = 1 };
+
+#define GOF_MAX_MODES 5      /* cv2 MOG2 default nmixtures                 */
+#define GOF_MAX_MORPH 8      /* ops in one pipeline's mat_morph list       */
+#define GOF_MAX_KSIZE 31     /* largest blur / structuring-element side    */
+
+typedef struct gof_ctx gof_ctx;
+typedef struct gof_mog2 gof_mog2;
+typedef struct gof_fd gof_fd;
+typedef struct gof_pipeline gof_pipeline;
+
+/* cv.createBackgroundSubtractorMOG2() defaults (pipeline.py:232). */
+typedef struct gof_mog2_params {
+    int history;              /* 500  */
+    int nmixtures;            /* 5    */
+    float var_threshold;      /* 16   Tb */
+    float background_ratio;   /* 0.9  TB */
+    float var_threshold_gen;  /* 9    Tg */
+    float var_init;           /* 15   */
+    float var_min;            /* 4    */
+    float var_max;            /* 75   */
+    float ct;                 /* 0.05 */
+    float tau;                /* 0.5  */
+    int detect_shadows;       /* 1    */
+    int shadow_value;         /* 127  */
+} gof_mog2_params;
+
+/* One mat_morph entry (pipeline.py:177-186, 473-475). */
+typedef struct gof_morph_op {
+    int op;                   /* GOF_ERODE | GOF_DILATE                    */
+    int kh, kw;               /* structuring-element size                  */
+    const uint8_t *kernel;    /* (kh, kw) uint8, non-zero = member; NULL = all ones */
+} gof_morph_op;
+
+/* Steps 1-3 of GOFPID.detect as one object (pipeline.py:461-476). */
+typedef struct gof_pipeline_desc {
+    int streams;              /* independent video streams stepped together (>= 1) */
+    int h, w, c;              /* frame geometry, c in {1, 3, 4}            */
+    int blur;                 /* GOF_BLUR_NONE | GOF_BLUR_GAUSS            */
+    int blur_kw, blur_kh;     /* odd                                        */
+    double blur_sigma_x, blur_sigma_y;
+    int detector;             /* GOF_DET_MOG2 | GOF_DET_FD                 */
+    gof_mog2_params mog2;
+    double fd_threshold;
+    int n_morph;
+    gof_morph_op morph[GOF_MAX_MORPH];
+} gof_pipeline_desc;
+
+/* ---- library / context ------------------------------------------------- */
+
+int gof_abi_version(void);
+const char *gof_strerror(int code);
+const char *gof_last_error(void);
+int gof_device_count(int *count);
+
+/* One context per (process, device): owns a HIP stream and scratch buffers. */
+int gof_create(int device, gof_ctx **out);
+void gof_destroy(gof_ctx *ctx);
+int gof_synchronize(gof_ctx *ctx);
+void *gof_stream(gof_ctx *ctx);        /* the context's hipStream_t */
+
+/* ---- step 1: blur  (replaces cv.GaussianBlur, pipeline.py:463-467) ------ */
+/* cv.GaussianBlur(src, (kw, kh), sigma_x, sigmaY = sigma_y) on uint8 with
+ * BORDER_REFLECT_101.  NB the reference passes blur['borderType'] as the 3rd
+ * positional argument, which cv2 binds to sigmaX. */
+int gof_gaussian_blur_host(gof_ctx *ctx, const uint8_t *src, uint8_t *dst, int h, int w, int c,
+                           int kw, int kh, double sigma_x, double sigma_y);
+int gof_gaussian_blur_dev(gof_ctx *ctx, const void *d_src, void *d_dst, int n_images, int h,
+                          int w, int c, int kw, int kh, double sigma_x, double sigma_y,
+                          void *stream);
+/* the 8.8 fixed-point taps the blur uses (host only, for tests) */
+int gof_gauss_kernel_q8(int n, double sigma, uint16_t *taps);
+
+/* ---- step 2a: MOG2  (replaces cv.createBackgroundSubtractorMOG2() and its
+ *      .apply(X), pipeline.py:232 and :470) --------------------------------- */
+void gof_mog2_default_params(gof_mog2_params *p);
+int gof_mog2_create(gof_ctx *ctx, int streams, int h, int w, int c, const gof_mog2_params *p,
+                    gof_mog2 **out);
+void gof_mog2_destroy(gof_mog2 *m);
+int gof_mog2_apply_host(gof_mog2 *m, const uint8_t *frames, uint8_t *masks);
+int gof_mog2_apply_dev(gof_mog2 *m, const void *d_frames, void *d_masks, void *stream);
+int gof_mog2_nframes(const gof_mog2 *m);
+/* Model as structure-of-arrays planes (the HBM layout), n = streams*h*w:
+ * weight[K][n], var[K][n], mean[K][c][n] float32, modes[n] uint8.  Entries of
+ * slots >= modes[i] are dead storage.  export -> host, import <- host: parity
+ * tests, checkpoint/restore and warm start of a replica. */
+int gof_mog2_export(gof_mog2 *m, float *weight, float *var, float *mean, uint8_t *modes);
+int gof_mog2_import(gof_mog2 *m, const float *weight, const float *var, const float *mean,
+                    const uint8_t *modes, int nframes);
+/* raw device view of the same planes (one allocation) for an RCCL broadcast */
+int gof_mog2_device_state(gof_mog2 *m, void **d_state, size_t *bytes);
+int gof_mog2_set_nframes(gof_mog2 *m, int nframes);
+
+/* ---- step 2b: frame differencing (replaces FrameDifferencing.apply,
+ *      segmentation.py:40-70) ---------------------------------------------- */
+int gof_fd_create(gof_ctx *ctx, int streams, int h, int w, int c, double threshold, gof_fd **out);
+void gof_fd_destroy(gof_fd *f);
+int gof_fd_apply_host(gof_fd *f, const uint8_t *frames, uint8_t *masks);
+int gof_fd_apply_dev(gof_fd *f, const void *d_frames, void *d_masks, void *stream);
+
+/* ---- step 3: morphology (replaces cv.erode / cv.dilate, pipeline.py:475) - */
+int gof_morph_host(gof_ctx *ctx, int op, const uint8_t *src, uint8_t *dst, int h, int w,
+                   const uint8_t *kernel, int kh, int kw);
+int gof_morph_dev(gof_ctx *ctx, int op, const void *d_src, void *d_dst, int n_images, int h,
+                  int w, const uint8_t *kernel, int kh, int kw, void *stream);
+
+/* ---- steps 1-3 fused (replaces pipeline.py:461-476 as a whole) ---------- */
+int gof_pipeline_create(gof_ctx *ctx, const gof_pipeline_desc *desc, gof_pipeline **out);
+void gof_pipeline_destroy(gof_pipeline *p);
+/* frames: streams x (h, w, c); masks: streams x (h, w) */
+int gof_pipeline_apply_host(gof_pipeline *p, const uint8_t *frames, uint8_t *masks);
+int gof_pipeline_apply_dev(gof_pipeline *p, const void *d_frames, void *d_masks, void *stream);
+gof_mog2 *gof_pipeline_mog2(gof_pipeline *p);   /* NULL for an FD pipeline */
+/* mean number of Gaussian modes in use per pixel (m-bar of the byte model) */
+int gof_pipeline_mean_modes(gof_pipeline *p, double *mean_modes);
+/* Algorithmic HBM bytes of one apply(), given m-bar:
+ *   *detector_bytes: the dominant kernel alone (fused blur + MOG2), per pixel
+ *       c + 1 + 2*(1 + 4*(2+c)*mbar)    = 6 + 40*mbar for BGR
+ *   *total_bytes: every kernel of the step (adds 2 B/px per morphology kernel
+ *       and 2*c B/px for a blur that is not fused). */
+int gof_pipeline_algorithmic_bytes(gof_pipeline *p, double mean_modes, double *total_bytes,
+                                   double *detector_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GOFPID_HIP_H */

@@ -1,0 +1,203 @@
+"""ctypes binding of libgofpid_hip.so (C ABI: include/gofpid_hip.h).
+
+There is no CPU fallback anywhere in this package: if the HIP library is not
+built, or no gfx950 device is visible, every entry point raises.
+"""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libgofpid_hip.so")
+
+OK, EINVAL, EHIP, ENOMEM, ENODEV = 0, 1, 2, 3, 4
+ERODE, DILATE = 0, 1
+DET_MOG2, DET_FD = 0, 1
+BLUR_NONE, BLUR_GAUSS = 0, 1
+MAX_MODES, MAX_MORPH, MAX_KSIZE = 5, 8, 31
+
+_u8p = C.POINTER(C.c_uint8)
+_f32p = C.POINTER(C.c_float)
+_u16p = C.POINTER(C.c_uint16)
+
+
+class Mog2Params(C.Structure):
+    _fields_ = [
+        ("history", C.c_int), ("nmixtures", C.c_int),
+        ("var_threshold", C.c_float), ("background_ratio", C.c_float),
+        ("var_threshold_gen", C.c_float), ("var_init", C.c_float),
+        ("var_min", C.c_float), ("var_max", C.c_float),
+        ("ct", C.c_float), ("tau", C.c_float),
+        ("detect_shadows", C.c_int), ("shadow_value", C.c_int),
+    ]
+
+
+class MorphOp(C.Structure):
+    _fields_ = [("op", C.c_int), ("kh", C.c_int), ("kw", C.c_int), ("kernel", _u8p)]
+
+
+class PipelineDesc(C.Structure):
+    _fields_ = [
+        ("streams", C.c_int), ("h", C.c_int), ("w", C.c_int), ("c", C.c_int),
+        ("blur", C.c_int), ("blur_kw", C.c_int), ("blur_kh", C.c_int),
+        ("blur_sigma_x", C.c_double), ("blur_sigma_y", C.c_double),
+        ("detector", C.c_int), ("mog2", Mog2Params), ("fd_threshold", C.c_double),
+        ("n_morph", C.c_int), ("morph", MorphOp * MAX_MORPH),
+    ]
+
+
+# name -> (restype, argtypes); also the list tests check against the header
+SIGNATURES = {
+    "gof_abi_version": (C.c_int, []),
+    "gof_strerror": (C.c_char_p, [C.c_int]),
+    "gof_last_error": (C.c_char_p, []),
+    "gof_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "gof_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "gof_destroy": (None, [C.c_void_p]),
+    "gof_synchronize": (C.c_int, [C.c_void_p]),
+    "gof_stream": (C.c_void_p, [C.c_void_p]),
+    "gof_gaussian_blur_host": (C.c_int, [C.c_void_p, _u8p, _u8p, C.c_int, C.c_int, C.c_int,
+                                         C.c_int, C.c_int, C.c_double, C.c_double]),
+    "gof_gaussian_blur_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
+                                        C.c_double, C.c_void_p]),
+    "gof_gauss_kernel_q8": (C.c_int, [C.c_int, C.c_double, _u16p]),
+    "gof_mog2_default_params": (None, [C.POINTER(Mog2Params)]),
+    "gof_mog2_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                  C.POINTER(Mog2Params), C.POINTER(C.c_void_p)]),
+    "gof_mog2_destroy": (None, [C.c_void_p]),
+    "gof_mog2_apply_host": (C.c_int, [C.c_void_p, _u8p, _u8p]),
+    "gof_mog2_apply_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gof_mog2_nframes": (C.c_int, [C.c_void_p]),
+    "gof_mog2_set_nframes": (C.c_int, [C.c_void_p, C.c_int]),
+    "gof_mog2_export": (C.c_int, [C.c_void_p, _f32p, _f32p, _f32p, _u8p]),
+    "gof_mog2_import": (C.c_int, [C.c_void_p, _f32p, _f32p, _f32p, _u8p, C.c_int]),
+    "gof_mog2_device_state": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p),
+                                        C.POINTER(C.c_size_t)]),
+    "gof_fd_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
+                                C.POINTER(C.c_void_p)]),
+    "gof_fd_destroy": (None, [C.c_void_p]),
+    "gof_fd_apply_host": (C.c_int, [C.c_void_p, _u8p, _u8p]),
+    "gof_fd_apply_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gof_morph_host": (C.c_int, [C.c_void_p, C.c_int, _u8p, _u8p, C.c_int, C.c_int, _u8p,
+                                 C.c_int, C.c_int]),
+    "gof_morph_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                C.c_int, _u8p, C.c_int, C.c_int, C.c_void_p]),
+    "gof_pipeline_create": (C.c_int, [C.c_void_p, C.POINTER(PipelineDesc),
+                                      C.POINTER(C.c_void_p)]),
+    "gof_pipeline_destroy": (None, [C.c_void_p]),
+    "gof_pipeline_apply_host": (C.c_int, [C.c_void_p, _u8p, _u8p]),
+    "gof_pipeline_apply_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gof_pipeline_mog2": (C.c_void_p, [C.c_void_p]),
+    "gof_pipeline_mean_modes": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    "gof_pipeline_algorithmic_bytes": (C.c_int, [C.c_void_p, C.c_double, C.POINTER(C.c_double),
+                                                 C.POINTER(C.c_double)]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load():
+    """dlopen the HIP library and type every entry point; raises if it is missing."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise ImportError(
+                    "pygofpid_amd: %s is not built (run `python -c 'import __graft_entry__ as g; "
+                    "g.build()'` or `make -C pygofpid_amd/csrc`); there is no CPU fallback"
+                    % LIB_PATH)
+            lib = C.CDLL(LIB_PATH)
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(lib, name)
+                fn.restype = res
+                fn.argtypes = args
+            _lib = lib
+    return _lib
+
+
+def check(rc):
+    """GOF_EINVAL -> ValueError (what the reference raises for bad shapes /
+    unknown methods, tests/test_pipeline.py:31-41,112-118); else RuntimeError."""
+    if rc == OK:
+        return
+    lib = load()
+    msg = lib.gof_last_error().decode() or lib.gof_strerror(rc).decode()
+    if rc == EINVAL:
+        raise ValueError(msg)
+    if rc == ENOMEM:
+        raise MemoryError(msg)
+    raise RuntimeError("%s (gof error %d)" % (msg, rc))
+
+
+def p8(a):
+    return a.ctypes.data_as(_u8p)
+
+
+def as_u8(x, name="X"):
+    x = np.asarray(x)
+    if x.dtype != np.uint8:
+        raise ValueError("%s must be uint8, got %s" % (name, x.dtype))
+    return np.ascontiguousarray(x)
+
+
+def hwc(x):
+    """(H,W) | (H,W,1) | (H,W,C) -> (array, h, w, c)"""
+    if x.ndim == 2:
+        return x, x.shape[0], x.shape[1], 1
+    if x.ndim == 3:
+        return x, x.shape[0], x.shape[1], x.shape[2]
+    raise ValueError("expected a (H,W) or (H,W,C) image, got shape %r" % (x.shape,))
+
+
+class Context:
+    """One per (process, device): stream + scratch (gof_create)."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        self.device = device
+        check(load().gof_create(int(device), C.byref(self._h)))
+
+    @property
+    def handle(self):
+        if not self._h:
+            raise RuntimeError("context destroyed")
+        return self._h
+
+    @property
+    def stream(self):
+        return load().gof_stream(self.handle)
+
+    def synchronize(self):
+        check(load().gof_synchronize(self.handle))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load().gof_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx = {}
+
+
+def default_context(device=None):
+    """Lazily created per-device context used by the cv2-style free functions."""
+    if device is None:
+        device = int(os.environ.get("GOFPID_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        n = C.c_int(0)
+        load().gof_device_count(C.byref(n))
+        if n.value > 0:
+            device %= n.value
+    ctx = _default_ctx.get(device)
+    if ctx is None:
+        ctx = _default_ctx[device] = Context(device)
+    return ctx

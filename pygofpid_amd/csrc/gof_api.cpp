@@ -1,0 +1,912 @@
+// C ABI of libgofpid_hip.so (include/gofpid_hip.h): contexts, the MOG2 / FD
+// state objects, the fused pipeline object and the host-buffer conveniences.
+// All arithmetic is in gof_kernels.hip; this file only owns memory, computes
+// the per-frame scalars cv2 computes on the host, and validates shapes before
+// any launch.
+#include "gofpid_hip.h"
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+#include <vector>
+
+#include "gof_kernels.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define GOF_HIP(expr)                                                                    \
+    do {                                                                                 \
+        hipError_t e_ = (expr);                                                          \
+        if (e_ != hipSuccess)                                                            \
+            return fail(e_ == hipErrorOutOfMemory ? GOF_ENOMEM                           \
+                        : e_ == hipErrorInvalidValue ? GOF_EINVAL : GOF_EHIP,            \
+                        "%s: %s", #expr, hipGetErrorString(e_));                         \
+    } while (0)
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes)
+    {
+        if (bytes <= cap)
+            return GOF_OK;
+        if (p)
+            (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        // + 256: dword-granular tile loads may touch the dword holding the last byte
+        GOF_HIP(hipMalloc(&p, bytes + 256));
+        cap = bytes;
+        return GOF_OK;
+    }
+    void release()
+    {
+        if (p)
+            (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+bool valid_channels(int c) { return c == 1 || c == 3 || c == 4; }
+
+}  // namespace
+
+struct gof_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    DevBuf in, out, tmp0, tmp1;   // scratch of the stateless host entry points
+};
+
+struct gof_mog2 {
+    gof_ctx *ctx = nullptr;
+    gof_mog2_params p{};
+    int streams = 0, h = 0, w = 0, c = 0;
+    int nframes = 0;
+    size_t np = 0;           // plane pitch in floats
+    size_t state_bytes = 0;
+    void *state = nullptr;   // [K*(2+c)] float planes of pitch np, then modes[np]
+    DevBuf in, out;
+    gofk::Mog2State view() const
+    {
+        gofk::Mog2State s;
+        s.planes = (float *)state;
+        s.modes = (uint8_t *)state + (size_t)p.nmixtures * (2 + c) * np * sizeof(float);
+        s.np = np;
+        return s;
+    }
+};
+
+struct gof_fd {
+    gof_ctx *ctx = nullptr;
+    int streams = 0, h = 0, w = 0, c = 0;
+    double threshold = 5;
+    bool has_prev = false;
+    int cur = 0;
+    DevBuf frame[2];         // ping-pong: frame[cur] is X_t, frame[cur^1] is X_{t-1}
+    DevBuf out;
+};
+
+struct gof_pipeline {
+    gof_ctx *ctx = nullptr;
+    gof_pipeline_desc d{};
+    std::vector<std::vector<uint8_t>> se;   // owned copies of the structuring elements
+    gofk::Taps taps{};
+    bool fuse_blur3 = false;
+    bool chain_ok = false;
+    gofk::RectChain chain{};
+    std::vector<gofk::SeBits> sebits;
+    gof_mog2 *mog2 = nullptr;
+    gof_fd *fd = nullptr;
+    DevBuf in, out, blurred, m0, m1;
+    unsigned long long *d_sum = nullptr;
+};
+
+namespace {
+
+int make_taps(int kw, int kh, double sx, double sy, gofk::Taps *t)
+{
+    if (kw < 1 || kh < 1 || !(kw & 1) || !(kh & 1) || kw > GOF_MAX_KSIZE || kh > GOF_MAX_KSIZE)
+        return fail(GOF_EINVAL, "Gaussian ksize must be odd and in [1, %d], got (%d, %d)",
+                    GOF_MAX_KSIZE, kw, kh);
+    if (sy <= 0)
+        sy = sx;
+    if (gof_gauss_kernel_q8(kw, sx, t->kx) || gof_gauss_kernel_q8(kh, sy, t->ky))
+        return fail(GOF_EINVAL, "bad Gaussian kernel");
+    t->nkx = kw;
+    t->nky = kh;
+    return GOF_OK;
+}
+
+int make_sebits(const uint8_t *k, int kh, int kw, gofk::SeBits *se)
+{
+    if (kh < 1 || kw < 1 || kh > GOF_MAX_KSIZE || kw > GOF_MAX_KSIZE)
+        return fail(GOF_EINVAL, "structuring element must be within %dx%d, got (%d, %d)",
+                    GOF_MAX_KSIZE, GOF_MAX_KSIZE, kh, kw);
+    memset(se, 0, sizeof(*se));
+    se->kh = kh;
+    se->kw = kw;
+    for (int y = 0; y < kh; y++)
+        for (int x = 0; x < kw; x++)
+            if (!k || k[y * kw + x])
+                se->rows[y] |= 1u << x;
+    return GOF_OK;
+}
+
+bool se_is_full_odd_rect(const gofk::SeBits &se)
+{
+    if (!(se.kh & 1) || !(se.kw & 1))
+        return false;
+    uint32_t full = se.kw == 32 ? 0xffffffffu : ((1u << se.kw) - 1);
+    for (int y = 0; y < se.kh; y++)
+        if (se.rows[y] != full)
+            return false;
+    return true;
+}
+
+int check_geom(int n, int h, int w, int c)
+{
+    if (n < 1 || h < 1 || w < 1 || !valid_channels(c))
+        return fail(GOF_EINVAL, "bad geometry: images=%d h=%d w=%d c=%d (c must be 1, 3 or 4)", n,
+                    h, w, c);
+    if ((double)n * h * w * 4.0 > 1.0e12)
+        return fail(GOF_EINVAL, "geometry too large");
+    return GOF_OK;
+}
+
+hipStream_t pick(gof_ctx *ctx, void *stream) { return stream ? (hipStream_t)stream : ctx->stream; }
+
+// cv2 BackgroundSubtractorMOG2Impl::apply, learningRate = -1 [OPENCV-RECALL]:
+//   ++nframes; lr = 1/min(2*nframes, history) in double;
+//   alphaT = float(lr); prune = float(-lr * fCT)
+gofk::Mog2Consts next_consts(gof_mog2 *m)
+{
+    ++m->nframes;
+    int d = 2 * m->nframes < m->p.history ? 2 * m->nframes : m->p.history;
+    double lr = 1.0 / (double)d;
+    gofk::Mog2Consts k;
+    k.alphaT = (float)lr;
+    k.alpha1 = 1.f - k.alphaT;
+    k.prune = (float)(-lr * m->p.ct);
+    k.Tb = m->p.var_threshold;
+    k.TB = m->p.background_ratio;
+    k.Tg = m->p.var_threshold_gen;
+    k.var_init = m->p.var_init;
+    k.var_min = m->p.var_min;
+    k.var_max = m->p.var_max;
+    k.tau = m->p.tau;
+    k.nmix = m->p.nmixtures;
+    k.detect_shadows = m->p.detect_shadows;
+    k.shadow_value = m->p.shadow_value;
+    return k;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gof_abi_version(void) { return GOF_ABI_VERSION; }
+
+const char *gof_strerror(int code)
+{
+    switch (code) {
+    case GOF_OK: return "ok";
+    case GOF_EINVAL: return "invalid argument";
+    case GOF_EHIP: return "HIP runtime error";
+    case GOF_ENOMEM: return "out of memory";
+    case GOF_ENODEV: return "no usable device";
+    default: return "unknown error";
+    }
+}
+
+const char *gof_last_error(void) { return g_err; }
+
+int gof_device_count(int *count)
+{
+    if (!count)
+        return fail(GOF_EINVAL, "count is NULL");
+    *count = 0;
+    hipError_t e = hipGetDeviceCount(count);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(GOF_ENODEV, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    return GOF_OK;
+}
+
+int gof_create(int device, gof_ctx **out)
+{
+    if (!out)
+        return fail(GOF_EINVAL, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n < 1)
+        return fail(GOF_ENODEV, "no HIP device visible");
+    if (device < 0 || device >= n)
+        return fail(GOF_EINVAL, "device %d out of range [0, %d)", device, n);
+    GOF_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    GOF_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(GOF_ENODEV, "device %d is %s; this library carries gfx950 code only", device,
+                    prop.gcnArchName);
+    gof_ctx *c = new (std::nothrow) gof_ctx;
+    if (!c)
+        return fail(GOF_ENOMEM, "host allocation failed");
+    c->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete c;
+        return fail(GOF_EHIP, "hipStreamCreate: %s", hipGetErrorString(e));
+    }
+    *out = c;
+    return GOF_OK;
+}
+
+void gof_destroy(gof_ctx *ctx)
+{
+    if (!ctx)
+        return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    ctx->in.release();
+    ctx->out.release();
+    ctx->tmp0.release();
+    ctx->tmp1.release();
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int gof_synchronize(gof_ctx *ctx)
+{
+    if (!ctx)
+        return fail(GOF_EINVAL, "ctx is NULL");
+    GOF_HIP(hipStreamSynchronize(ctx->stream));
+    return GOF_OK;
+}
+
+void *gof_stream(gof_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+/* ---- blur ---------------------------------------------------------------- */
+
+int gof_gauss_kernel_q8(int n, double sigma, uint16_t *taps)
+{
+    // cv2 getGaussianKernelBitExact + getGaussianKernelFixedPoint_ED [OPENCV-RECALL],
+    // side taps rounded to 1/256 with the error carried forward,
+    // centre tap = 256 - 2*sum(side); sigma <= 0 uses cv2's small fixed tables.
+    if (n < 1 || !(n & 1) || n > 255 || !taps)
+        return GOF_EINVAL;
+    if (sigma <= 0) {
+        static const uint16_t t1[] = {256}, t3[] = {64, 128, 64}, t5[] = {16, 64, 96, 64, 16},
+                              t7[] = {8, 28, 56, 72, 56, 28, 8},
+                              t9[] = {4, 13, 30, 51, 60, 51, 30, 13, 4};
+        const uint16_t *t = n == 1 ? t1 : n == 3 ? t3 : n == 5 ? t5 : n == 7 ? t7 : n == 9 ? t9 : nullptr;
+        if (t) {
+            memcpy(taps, t, (size_t)n * sizeof(uint16_t));
+            return GOF_OK;
+        }
+        sigma = ((n - 1) * 0.5 - 1) * 0.3 + 0.8;
+    }
+    const int half = n / 2;
+    std::vector<double> g((size_t)n);
+    double sum = 0;
+    const double s2 = -0.5 / (sigma * sigma);
+    for (int i = 0; i < n; i++) {
+        double x = i - half;
+        g[(size_t)i] = exp(s2 * x * x);
+        sum += g[(size_t)i];
+    }
+    double err = 0;
+    long acc = 0;
+    for (int i = 0; i < half; i++) {
+        double adj = g[(size_t)i] / sum * 256.0 + err;
+        long v = lrint(adj);
+        err = adj - (double)v;
+        taps[i] = taps[n - 1 - i] = (uint16_t)v;
+        acc += 2 * v;
+    }
+    taps[half] = (uint16_t)(256 - acc);
+    return GOF_OK;
+}
+
+int gof_gaussian_blur_dev(gof_ctx *ctx, const void *d_src, void *d_dst, int n_images, int h, int w,
+                          int c, int kw, int kh, double sigma_x, double sigma_y, void *stream)
+{
+    if (!ctx || !d_src || !d_dst)
+        return fail(GOF_EINVAL, "NULL argument");
+    if (d_src == d_dst)
+        return fail(GOF_EINVAL, "blur cannot run in place");
+    int rc = check_geom(n_images, h, w, c);
+    if (rc)
+        return rc;
+    gofk::Taps t;
+    if ((rc = make_taps(kw, kh, sigma_x, sigma_y, &t)))
+        return rc;
+    GOF_HIP(hipSetDevice(ctx->device));
+    GOF_HIP(gofk::blur_sep_q8((const uint8_t *)d_src, (uint8_t *)d_dst, n_images, h, w, c, t,
+                              pick(ctx, stream)));
+    return GOF_OK;
+}
+
+int gof_gaussian_blur_host(gof_ctx *ctx, const uint8_t *src, uint8_t *dst, int h, int w, int c,
+                           int kw, int kh, double sigma_x, double sigma_y)
+{
+    if (!ctx || !src || !dst)
+        return fail(GOF_EINVAL, "NULL argument");
+    int rc = check_geom(1, h, w, c);
+    if (rc)
+        return rc;
+    size_t bytes = (size_t)h * w * c;
+    GOF_HIP(hipSetDevice(ctx->device));
+    if ((rc = ctx->in.reserve(bytes)) || (rc = ctx->out.reserve(bytes)))
+        return rc;
+    GOF_HIP(hipMemcpyAsync(ctx->in.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    rc = gof_gaussian_blur_dev(ctx, ctx->in.p, ctx->out.p, 1, h, w, c, kw, kh, sigma_x, sigma_y,
+                               nullptr);
+    if (rc)
+        return rc;
+    GOF_HIP(hipMemcpyAsync(dst, ctx->out.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    GOF_HIP(hipStreamSynchronize(ctx->stream));
+    return GOF_OK;
+}
+
+/* ---- MOG2 ---------------------------------------------------------------- */
+
+void gof_mog2_default_params(gof_mog2_params *p)
+{
+    if (!p)
+        return;
+    p->history = 500;
+    p->nmixtures = 5;
+    p->var_threshold = 16.f;
+    p->background_ratio = 0.9f;
+    p->var_threshold_gen = 9.f;
+    p->var_init = 15.f;
+    p->var_min = 4.f;
+    p->var_max = 75.f;
+    p->ct = 0.05f;
+    p->tau = 0.5f;
+    p->detect_shadows = 1;
+    p->shadow_value = 127;
+}
+
+int gof_mog2_create(gof_ctx *ctx, int streams, int h, int w, int c, const gof_mog2_params *p,
+                    gof_mog2 **out)
+{
+    if (!ctx || !out)
+        return fail(GOF_EINVAL, "NULL argument");
+    *out = nullptr;
+    int rc = check_geom(streams, h, w, c);
+    if (rc)
+        return rc;
+    gof_mog2_params pp;
+    if (p)
+        pp = *p;
+    else
+        gof_mog2_default_params(&pp);
+    if (pp.nmixtures < 1 || pp.nmixtures > GOF_MAX_MODES || pp.history < 1 ||
+        pp.shadow_value < 0 || pp.shadow_value > 255)
+        return fail(GOF_EINVAL, "bad MOG2 parameters (nmixtures in [1,%d], history >= 1)",
+                    GOF_MAX_MODES);
+    gof_mog2 *m = new (std::nothrow) gof_mog2;
+    if (!m)
+        return fail(GOF_ENOMEM, "host allocation failed");
+    m->ctx = ctx;
+    m->p = pp;
+    m->streams = streams;
+    m->h = h;
+    m->w = w;
+    m->c = c;
+    size_t n = (size_t)streams * h * w;
+    m->np = (n + 63) & ~(size_t)63;   // planes start on 256-B boundaries
+    m->state_bytes = (size_t)pp.nmixtures * (2 + c) * m->np * sizeof(float) + m->np;
+    GOF_HIP(hipSetDevice(ctx->device));
+    hipError_t e = hipMalloc(&m->state, m->state_bytes);
+    if (e != hipSuccess) {
+        delete m;
+        return fail(GOF_ENOMEM, "hipMalloc(%zu B of MOG2 state): %s", m->state_bytes,
+                    hipGetErrorString(e));
+    }
+    e = hipMemsetAsync(m->state, 0, m->state_bytes, ctx->stream);
+    if (e != hipSuccess) {
+        (void)hipFree(m->state);
+        delete m;
+        return fail(GOF_EHIP, "hipMemsetAsync: %s", hipGetErrorString(e));
+    }
+    *out = m;
+    return GOF_OK;
+}
+
+void gof_mog2_destroy(gof_mog2 *m)
+{
+    if (!m)
+        return;
+    (void)hipSetDevice(m->ctx->device);
+    (void)hipStreamSynchronize(m->ctx->stream);
+    if (m->state)
+        (void)hipFree(m->state);
+    m->in.release();
+    m->out.release();
+    delete m;
+}
+
+int gof_mog2_nframes(const gof_mog2 *m) { return m ? m->nframes : -1; }
+
+int gof_mog2_set_nframes(gof_mog2 *m, int nframes)
+{
+    if (!m || nframes < 0)
+        return fail(GOF_EINVAL, "bad argument");
+    m->nframes = nframes;
+    return GOF_OK;
+}
+
+int gof_mog2_apply_dev(gof_mog2 *m, const void *d_frames, void *d_masks, void *stream)
+{
+    if (!m || !d_frames || !d_masks)
+        return fail(GOF_EINVAL, "NULL argument");
+    GOF_HIP(hipSetDevice(m->ctx->device));
+    gofk::Mog2Consts k = next_consts(m);
+    gofk::Taps none{};
+    hipError_t e = gofk::mog2_apply((const uint8_t *)d_frames, (uint8_t *)d_masks, m->view(),
+                                    m->streams, m->h, m->w, m->c, k, false, none,
+                                    pick(m->ctx, stream));
+    if (e != hipSuccess) {
+        --m->nframes;
+        return fail(GOF_EHIP, "mog2 launch: %s", hipGetErrorString(e));
+    }
+    return GOF_OK;
+}
+
+int gof_mog2_apply_host(gof_mog2 *m, const uint8_t *frames, uint8_t *masks)
+{
+    if (!m || !frames || !masks)
+        return fail(GOF_EINVAL, "NULL argument");
+    size_t npx = (size_t)m->streams * m->h * m->w;
+    int rc;
+    GOF_HIP(hipSetDevice(m->ctx->device));
+    if ((rc = m->in.reserve(npx * m->c)) || (rc = m->out.reserve(npx)))
+        return rc;
+    hipStream_t s = m->ctx->stream;
+    GOF_HIP(hipMemcpyAsync(m->in.p, frames, npx * m->c, hipMemcpyHostToDevice, s));
+    if ((rc = gof_mog2_apply_dev(m, m->in.p, m->out.p, nullptr)))
+        return rc;
+    GOF_HIP(hipMemcpyAsync(masks, m->out.p, npx, hipMemcpyDeviceToHost, s));
+    GOF_HIP(hipStreamSynchronize(s));
+    return GOF_OK;
+}
+
+int gof_mog2_export(gof_mog2 *m, float *weight, float *var, float *mean, uint8_t *modes)
+{
+    if (!m || !weight || !var || !mean || !modes)
+        return fail(GOF_EINVAL, "NULL argument");
+    GOF_HIP(hipSetDevice(m->ctx->device));
+    hipStream_t s = m->ctx->stream;
+    const size_t n = (size_t)m->streams * m->h * m->w, np = m->np;
+    const int K = m->p.nmixtures, C = m->c, F = 2 + C;
+    const float *pl = (const float *)m->state;
+    for (int k = 0; k < K; k++) {
+        GOF_HIP(hipMemcpyAsync(weight + (size_t)k * n, pl + ((size_t)k * F + 0) * np,
+                               n * sizeof(float), hipMemcpyDeviceToHost, s));
+        GOF_HIP(hipMemcpyAsync(var + (size_t)k * n, pl + ((size_t)k * F + 1) * np,
+                               n * sizeof(float), hipMemcpyDeviceToHost, s));
+        for (int ch = 0; ch < C; ch++)
+            GOF_HIP(hipMemcpyAsync(mean + ((size_t)k * C + ch) * n,
+                                   pl + ((size_t)k * F + 2 + ch) * np, n * sizeof(float),
+                                   hipMemcpyDeviceToHost, s));
+    }
+    GOF_HIP(hipMemcpyAsync(modes, m->view().modes, n, hipMemcpyDeviceToHost, s));
+    GOF_HIP(hipStreamSynchronize(s));
+    return GOF_OK;
+}
+
+int gof_mog2_import(gof_mog2 *m, const float *weight, const float *var, const float *mean,
+                    const uint8_t *modes, int nframes)
+{
+    if (!m || !weight || !var || !mean || !modes || nframes < 0)
+        return fail(GOF_EINVAL, "bad argument");
+    GOF_HIP(hipSetDevice(m->ctx->device));
+    hipStream_t s = m->ctx->stream;
+    const size_t n = (size_t)m->streams * m->h * m->w, np = m->np;
+    const int K = m->p.nmixtures, C = m->c, F = 2 + C;
+    for (size_t i = 0; i < n; i++)
+        if (modes[i] > K)
+            return fail(GOF_EINVAL, "modes[%zu] = %d exceeds nmixtures %d", i, modes[i], K);
+    float *pl = (float *)m->state;
+    for (int k = 0; k < K; k++) {
+        GOF_HIP(hipMemcpyAsync(pl + ((size_t)k * F + 0) * np, weight + (size_t)k * n,
+                               n * sizeof(float), hipMemcpyHostToDevice, s));
+        GOF_HIP(hipMemcpyAsync(pl + ((size_t)k * F + 1) * np, var + (size_t)k * n,
+                               n * sizeof(float), hipMemcpyHostToDevice, s));
+        for (int ch = 0; ch < C; ch++)
+            GOF_HIP(hipMemcpyAsync(pl + ((size_t)k * F + 2 + ch) * np,
+                                   mean + ((size_t)k * C + ch) * n, n * sizeof(float),
+                                   hipMemcpyHostToDevice, s));
+    }
+    GOF_HIP(hipMemcpyAsync(m->view().modes, modes, n, hipMemcpyHostToDevice, s));
+    GOF_HIP(hipStreamSynchronize(s));
+    m->nframes = nframes;
+    return GOF_OK;
+}
+
+int gof_mog2_device_state(gof_mog2 *m, void **d_state, size_t *bytes)
+{
+    if (!m || !d_state || !bytes)
+        return fail(GOF_EINVAL, "NULL argument");
+    *d_state = m->state;
+    *bytes = m->state_bytes;
+    return GOF_OK;
+}
+
+/* ---- frame differencing -------------------------------------------------- */
+
+int gof_fd_create(gof_ctx *ctx, int streams, int h, int w, int c, double threshold, gof_fd **out)
+{
+    if (!ctx || !out)
+        return fail(GOF_EINVAL, "NULL argument");
+    *out = nullptr;
+    int rc = check_geom(streams, h, w, c);
+    if (rc)
+        return rc;
+    if (!(threshold == threshold))
+        return fail(GOF_EINVAL, "threshold is NaN");
+    gof_fd *f = new (std::nothrow) gof_fd;
+    if (!f)
+        return fail(GOF_ENOMEM, "host allocation failed");
+    f->ctx = ctx;
+    f->streams = streams;
+    f->h = h;
+    f->w = w;
+    f->c = c;
+    f->threshold = threshold;
+    *out = f;
+    return GOF_OK;
+}
+
+void gof_fd_destroy(gof_fd *f)
+{
+    if (!f)
+        return;
+    (void)hipSetDevice(f->ctx->device);
+    (void)hipStreamSynchronize(f->ctx->stream);
+    f->frame[0].release();
+    f->frame[1].release();
+    f->out.release();
+    delete f;
+}
+
+namespace {
+// cv.threshold on uint8 floors a float threshold [OPENCV-RECALL]; clamp so the
+// int compare stays meaningful for any double.
+int fd_ithr(double thr)
+{
+    double f = floor(thr);
+    return f < -1 ? -1 : (f > 255 ? 255 : (int)f);
+}
+}  // namespace
+
+/* The device entry point keeps its own copy of X_t as next call's X_{t-1}: the
+ * reference keeps a *reference* to X (segmentation.py:66), which is the same
+ * thing as long as the caller does not overwrite X, and safer when it does. */
+int gof_fd_apply_dev(gof_fd *f, const void *d_frames, void *d_masks, void *stream)
+{
+    if (!f || !d_frames || !d_masks)
+        return fail(GOF_EINVAL, "NULL argument");
+    GOF_HIP(hipSetDevice(f->ctx->device));
+    hipStream_t s = pick(f->ctx, stream);
+    size_t bytes = (size_t)f->streams * f->h * f->w * f->c;
+    int rc;
+    if ((rc = f->frame[0].reserve(bytes)) || (rc = f->frame[1].reserve(bytes)))
+        return rc;
+    const void *prev = f->frame[f->cur ^ 1].p;
+    GOF_HIP(gofk::fd_apply((const uint8_t *)d_frames, (const uint8_t *)prev, f->has_prev,
+                           fd_ithr(f->threshold), (uint8_t *)d_masks, f->streams, f->h, f->w, f->c,
+                           s));
+    GOF_HIP(hipMemcpyAsync(f->frame[f->cur].p, d_frames, bytes, hipMemcpyDeviceToDevice, s));
+    f->cur ^= 1;
+    f->has_prev = true;
+    return GOF_OK;
+}
+
+int gof_fd_apply_host(gof_fd *f, const uint8_t *frames, uint8_t *masks)
+{
+    if (!f || !frames || !masks)
+        return fail(GOF_EINVAL, "NULL argument");
+    GOF_HIP(hipSetDevice(f->ctx->device));
+    hipStream_t s = f->ctx->stream;
+    size_t npx = (size_t)f->streams * f->h * f->w, bytes = npx * f->c;
+    int rc;
+    if ((rc = f->frame[0].reserve(bytes)) || (rc = f->frame[1].reserve(bytes)) ||
+        (rc = f->out.reserve(npx)))
+        return rc;
+    // upload straight into the ping-pong slot: no device-to-device copy
+    void *cur = f->frame[f->cur].p;
+    const void *prev = f->frame[f->cur ^ 1].p;
+    GOF_HIP(hipMemcpyAsync(cur, frames, bytes, hipMemcpyHostToDevice, s));
+    GOF_HIP(gofk::fd_apply((const uint8_t *)cur, (const uint8_t *)prev, f->has_prev,
+                           fd_ithr(f->threshold), (uint8_t *)f->out.p, f->streams, f->h, f->w,
+                           f->c, s));
+    GOF_HIP(hipMemcpyAsync(masks, f->out.p, npx, hipMemcpyDeviceToHost, s));
+    GOF_HIP(hipStreamSynchronize(s));
+    f->cur ^= 1;
+    f->has_prev = true;
+    return GOF_OK;
+}
+
+/* ---- morphology ---------------------------------------------------------- */
+
+int gof_morph_dev(gof_ctx *ctx, int op, const void *d_src, void *d_dst, int n_images, int h, int w,
+                  const uint8_t *kernel, int kh, int kw, void *stream)
+{
+    if (!ctx || !d_src || !d_dst)
+        return fail(GOF_EINVAL, "NULL argument");
+    if (d_src == d_dst)
+        return fail(GOF_EINVAL, "morphology cannot run in place");
+    if (op != GOF_ERODE && op != GOF_DILATE)
+        return fail(GOF_EINVAL, "op must be GOF_ERODE or GOF_DILATE");
+    int rc = check_geom(n_images, h, w, 1);
+    if (rc)
+        return rc;
+    gofk::SeBits se;
+    if ((rc = make_sebits(kernel, kh, kw, &se)))
+        return rc;
+    GOF_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = pick(ctx, stream);
+    if (se_is_full_odd_rect(se)) {
+        gofk::RectChain ch{};
+        ch.n = 1;
+        ch.op[0] = op;
+        ch.rx[0] = kw / 2;
+        ch.ry[0] = kh / 2;
+        if (gofk::morph_rect_chain_supported(ch)) {
+            GOF_HIP(gofk::morph_rect_chain((const uint8_t *)d_src, (uint8_t *)d_dst, n_images, h, w,
+                                           ch, s));
+            return GOF_OK;
+        }
+    }
+    GOF_HIP(gofk::morph_generic(op, (const uint8_t *)d_src, (uint8_t *)d_dst, n_images, h, w, se, s));
+    return GOF_OK;
+}
+
+int gof_morph_host(gof_ctx *ctx, int op, const uint8_t *src, uint8_t *dst, int h, int w,
+                   const uint8_t *kernel, int kh, int kw)
+{
+    if (!ctx || !src || !dst)
+        return fail(GOF_EINVAL, "NULL argument");
+    int rc = check_geom(1, h, w, 1);
+    if (rc)
+        return rc;
+    size_t bytes = (size_t)h * w;
+    GOF_HIP(hipSetDevice(ctx->device));
+    if ((rc = ctx->in.reserve(bytes)) || (rc = ctx->out.reserve(bytes)))
+        return rc;
+    GOF_HIP(hipMemcpyAsync(ctx->in.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = gof_morph_dev(ctx, op, ctx->in.p, ctx->out.p, 1, h, w, kernel, kh, kw, nullptr)))
+        return rc;
+    GOF_HIP(hipMemcpyAsync(dst, ctx->out.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    GOF_HIP(hipStreamSynchronize(ctx->stream));
+    return GOF_OK;
+}
+
+/* ---- fused pipeline ------------------------------------------------------ */
+
+int gof_pipeline_create(gof_ctx *ctx, const gof_pipeline_desc *desc, gof_pipeline **out)
+{
+    if (!ctx || !desc || !out)
+        return fail(GOF_EINVAL, "NULL argument");
+    *out = nullptr;
+    int rc = check_geom(desc->streams, desc->h, desc->w, desc->c);
+    if (rc)
+        return rc;
+    if (desc->n_morph < 0 || desc->n_morph > GOF_MAX_MORPH)
+        return fail(GOF_EINVAL, "n_morph must be in [0, %d]", GOF_MAX_MORPH);
+    if (desc->detector != GOF_DET_MOG2 && desc->detector != GOF_DET_FD)
+        return fail(GOF_EINVAL, "Unknown method for foreground detection");
+    if (desc->blur != GOF_BLUR_NONE && desc->blur != GOF_BLUR_GAUSS)
+        return fail(GOF_EINVAL, "unknown blur kind %d", desc->blur);
+    gof_pipeline *p = new (std::nothrow) gof_pipeline;
+    if (!p)
+        return fail(GOF_ENOMEM, "host allocation failed");
+    p->ctx = ctx;
+    p->d = *desc;
+    auto bail = [&](int code) {
+        gof_pipeline_destroy(p);
+        return code;
+    };
+    if (desc->blur == GOF_BLUR_GAUSS) {
+        if ((rc = make_taps(desc->blur_kw, desc->blur_kh, desc->blur_sigma_x, desc->blur_sigma_y,
+                            &p->taps)))
+            return bail(rc);
+        p->fuse_blur3 = desc->detector == GOF_DET_MOG2 && p->taps.nkx == 3 && p->taps.nky == 3;
+    }
+    bool all_rect = desc->n_morph > 0;
+    p->chain.n = desc->n_morph;
+    for (int i = 0; i < desc->n_morph; i++) {
+        const gof_morph_op &o = desc->morph[i];
+        if (o.op != GOF_ERODE && o.op != GOF_DILATE)
+            return bail(fail(GOF_EINVAL, "morph[%d].op must be GOF_ERODE or GOF_DILATE", i));
+        gofk::SeBits se;
+        if ((rc = make_sebits(o.kernel, o.kh, o.kw, &se)))
+            return bail(rc);
+        p->sebits.push_back(se);
+        all_rect = all_rect && se_is_full_odd_rect(se);
+        p->chain.op[i] = o.op;
+        p->chain.rx[i] = o.kw / 2;
+        p->chain.ry[i] = o.kh / 2;
+        p->d.morph[i].kernel = nullptr;   // the bits are owned now; drop the borrowed pointer
+    }
+    p->chain_ok = all_rect && gofk::morph_rect_chain_supported(p->chain);
+    if (desc->detector == GOF_DET_MOG2) {
+        if ((rc = gof_mog2_create(ctx, desc->streams, desc->h, desc->w, desc->c, &desc->mog2,
+                                  &p->mog2)))
+            return bail(rc);
+    } else {
+        if ((rc = gof_fd_create(ctx, desc->streams, desc->h, desc->w, desc->c, desc->fd_threshold,
+                                &p->fd)))
+            return bail(rc);
+    }
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e == hipSuccess)
+        e = hipMalloc((void **)&p->d_sum, sizeof(unsigned long long));
+    if (e != hipSuccess)
+        return bail(fail(GOF_EHIP, "pipeline scratch: %s", hipGetErrorString(e)));
+    *out = p;
+    return GOF_OK;
+}
+
+void gof_pipeline_destroy(gof_pipeline *p)
+{
+    if (!p)
+        return;
+    (void)hipSetDevice(p->ctx->device);
+    (void)hipStreamSynchronize(p->ctx->stream);
+    gof_mog2_destroy(p->mog2);
+    gof_fd_destroy(p->fd);
+    p->in.release();
+    p->out.release();
+    p->blurred.release();
+    p->m0.release();
+    p->m1.release();
+    if (p->d_sum)
+        (void)hipFree(p->d_sum);
+    delete p;
+}
+
+gof_mog2 *gof_pipeline_mog2(gof_pipeline *p) { return p ? p->mog2 : nullptr; }
+
+int gof_pipeline_apply_dev(gof_pipeline *p, const void *d_frames, void *d_masks, void *stream)
+{
+    if (!p || !d_frames || !d_masks)
+        return fail(GOF_EINVAL, "NULL argument");
+    GOF_HIP(hipSetDevice(p->ctx->device));
+    hipStream_t s = pick(p->ctx, stream);
+    const gof_pipeline_desc &d = p->d;
+    const size_t npx = (size_t)d.streams * d.h * d.w;
+    int rc;
+
+    // step 1 (pipeline.py:462-467) -- unless it is fused into step 2
+    const uint8_t *x = (const uint8_t *)d_frames;
+    if (d.blur == GOF_BLUR_GAUSS && !p->fuse_blur3) {
+        if ((rc = p->blurred.reserve(npx * d.c)))
+            return rc;
+        GOF_HIP(gofk::blur_sep_q8(x, (uint8_t *)p->blurred.p, d.streams, d.h, d.w, d.c, p->taps, s));
+        x = (const uint8_t *)p->blurred.p;
+    }
+
+    // step 2 (pipeline.py:470)
+    uint8_t *det_out = (uint8_t *)d_masks;
+    if (d.n_morph > 0) {
+        if ((rc = p->m0.reserve(npx)))
+            return rc;
+        det_out = (uint8_t *)p->m0.p;
+    }
+    if (p->mog2) {
+        gofk::Mog2Consts k = next_consts(p->mog2);
+        hipError_t e = gofk::mog2_apply(x, det_out, p->mog2->view(), d.streams, d.h, d.w, d.c, k,
+                                        p->fuse_blur3, p->taps, s);
+        if (e != hipSuccess) {
+            --p->mog2->nframes;
+            return fail(GOF_EHIP, "mog2 launch: %s", hipGetErrorString(e));
+        }
+    } else {
+        if ((rc = gof_fd_apply_dev(p->fd, x, det_out, s)))
+            return rc;
+    }
+
+    // step 3 (pipeline.py:473-475)
+    if (d.n_morph > 0) {
+        if (p->chain_ok) {
+            GOF_HIP(gofk::morph_rect_chain(det_out, (uint8_t *)d_masks, d.streams, d.h, d.w,
+                                           p->chain, s));
+        } else {
+            if (d.n_morph > 1 && (rc = p->m1.reserve(npx)))
+                return rc;
+            const uint8_t *src = det_out;
+            for (int i = 0; i < d.n_morph; i++) {
+                uint8_t *dst = i == d.n_morph - 1 ? (uint8_t *)d_masks
+                               : (src == (const uint8_t *)p->m0.p ? (uint8_t *)p->m1.p
+                                                                   : (uint8_t *)p->m0.p);
+                GOF_HIP(gofk::morph_generic(d.morph[i].op, src, dst, d.streams, d.h, d.w,
+                                            p->sebits[(size_t)i], s));
+                src = dst;
+            }
+        }
+    }
+    return GOF_OK;
+}
+
+int gof_pipeline_apply_host(gof_pipeline *p, const uint8_t *frames, uint8_t *masks)
+{
+    if (!p || !frames || !masks)
+        return fail(GOF_EINVAL, "NULL argument");
+    GOF_HIP(hipSetDevice(p->ctx->device));
+    hipStream_t s = p->ctx->stream;
+    const size_t npx = (size_t)p->d.streams * p->d.h * p->d.w;
+    int rc;
+    if ((rc = p->in.reserve(npx * p->d.c)) || (rc = p->out.reserve(npx)))
+        return rc;
+    GOF_HIP(hipMemcpyAsync(p->in.p, frames, npx * p->d.c, hipMemcpyHostToDevice, s));
+    if ((rc = gof_pipeline_apply_dev(p, p->in.p, p->out.p, nullptr)))
+        return rc;
+    GOF_HIP(hipMemcpyAsync(masks, p->out.p, npx, hipMemcpyDeviceToHost, s));
+    GOF_HIP(hipStreamSynchronize(s));
+    return GOF_OK;
+}
+
+int gof_pipeline_mean_modes(gof_pipeline *p, double *mean_modes)
+{
+    if (!p || !mean_modes)
+        return fail(GOF_EINVAL, "NULL argument");
+    *mean_modes = 0.0;
+    if (!p->mog2)
+        return GOF_OK;
+    GOF_HIP(hipSetDevice(p->ctx->device));
+    hipStream_t s = p->ctx->stream;
+    const size_t n = (size_t)p->d.streams * p->d.h * p->d.w;
+    unsigned long long sum = 0;
+    GOF_HIP(hipMemsetAsync(p->d_sum, 0, sizeof(sum), s));
+    GOF_HIP(gofk::sum_modes(p->mog2->view().modes, n, p->d_sum, s));
+    GOF_HIP(hipMemcpyAsync(&sum, p->d_sum, sizeof(sum), hipMemcpyDeviceToHost, s));
+    GOF_HIP(hipStreamSynchronize(s));
+    *mean_modes = (double)sum / (double)n;
+    return GOF_OK;
+}
+
+int gof_pipeline_algorithmic_bytes(gof_pipeline *p, double mean_modes, double *total_bytes,
+                                   double *detector_bytes)
+{
+    if (!p || !total_bytes || !detector_bytes)
+        return fail(GOF_EINVAL, "NULL argument");
+    const gof_pipeline_desc &d = p->d;
+    const double npx = (double)d.streams * d.h * d.w;
+    // detector kernel: frame in, mask out, and its state
+    double det = d.c + 1.0;
+    if (p->mog2)
+        det += 2.0 * (1.0 + 4.0 * (2 + d.c) * mean_modes);   // model read + write
+    else
+        det += 2.0 * d.c;                                      // X_{t-1} read, X_t kept
+    double tot = det;
+    if (d.blur == GOF_BLUR_GAUSS && !p->fuse_blur3)
+        tot += 2.0 * d.c;                                      // blurred image written + read
+    const int morph_kernels = d.n_morph == 0 ? 0 : (p->chain_ok ? 1 : d.n_morph);
+    tot += 2.0 * morph_kernels;                                // each reads a mask, writes a mask
+    *total_bytes = npx * tot;
+    *detector_bytes = npx * det;
+    return GOF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,74 @@
+// Internal launch interface between the C ABI (gof_api.cpp) and the gfx950
+// kernels (gof_kernels.hip).  Not installed; the public surface is
+// include/gofpid_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gofk {
+
+constexpr int kMaxModes = 5;
+constexpr int kMaxKsize = 31;
+
+// Per-frame MOG2 scalars (cv2 BackgroundSubtractorMOG2Impl::apply computes the
+// rates on the host once per frame; restated in gof_api.cpp).
+struct Mog2Consts {
+    float alphaT, alpha1, prune;
+    float Tb, TB, Tg;
+    float var_init, var_min, var_max, tau;
+    int nmix;
+    int detect_shadows;
+    int shadow_value;
+};
+
+// Structure-of-arrays model in HBM, np = plane pitch in floats (>= streams*h*w):
+//   plane(m, f) = state + (m*(2+C) + f) * np ; f = 0 weight, 1 variance, 2+ch mean[ch]
+struct Mog2State {
+    float *planes;
+    uint8_t *modes;
+    size_t np;
+};
+
+struct Taps {
+    uint16_t kx[kMaxKsize];
+    uint16_t ky[kMaxKsize];
+    int nkx, nky;
+};
+
+struct SeBits {            // structuring element, bit dx of rows[dy] = member
+    uint32_t rows[kMaxKsize];
+    int kh, kw;
+};
+
+struct RectChain {         // fused chain of rectangular erode/dilate ops
+    int n;
+    int op[8];
+    int rx[8], ry[8];      // half sizes (odd kernels only)
+};
+
+// images: n_img dense (h, w, c) uint8 frames back to back.
+hipError_t blur_sep_q8(const uint8_t *src, uint8_t *dst, int n_img, int h, int w, int c,
+                       const Taps &t, hipStream_t s);
+
+// mask[n_img][h][w] <- MOG2 update of state with frame[n_img][h][w][c].
+// fused_blur3: the frame is first blurred with the 3x3 taps t (REFLECT_101)
+// inside the same kernel (LDS-staged tile), no intermediate image.
+hipError_t mog2_apply(const uint8_t *frame, uint8_t *mask, const Mog2State &st, int n_img, int h,
+                      int w, int c, const Mog2Consts &k, bool fused_blur3, const Taps &t,
+                      hipStream_t s);
+
+hipError_t fd_apply(const uint8_t *cur, const uint8_t *prev, bool has_prev, int ithr,
+                    uint8_t *mask, int n_img, int h, int w, int c, hipStream_t s);
+
+hipError_t morph_generic(int op, const uint8_t *src, uint8_t *dst, int n_img, int h, int w,
+                         const SeBits &se, hipStream_t s);
+
+// all ops rectangular with odd sizes: one kernel, intermediates stay in LDS.
+hipError_t morph_rect_chain(const uint8_t *src, uint8_t *dst, int n_img, int h, int w,
+                            const RectChain &ch, hipStream_t s);
+bool morph_rect_chain_supported(const RectChain &ch);
+
+// sum of modes[] (for m-bar); out is a device uint64 accumulator, zeroed by caller.
+hipError_t sum_modes(const uint8_t *modes, size_t n, unsigned long long *out, hipStream_t s);
+
+}  // namespace gofk

@@ -1,0 +1,152 @@
+"""Steps 1-3 of GOFPID.detect as one GPU object (gof_pipeline in the C ABI).
+
+`ForegroundPipeline` is what `GOFPID.detect` uses when its blur / detector /
+morphology configuration is made of this package's own callables, and what
+bench.py drives with device-resident frames.  `streams` independent videos of
+one geometry are stepped together in each launch (one background model each).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+class ForegroundPipeline:
+    """blur -> MOG2 | FD -> erode/dilate chain  [REF pipeline.py:461-476].
+
+    Parameters
+    ----------
+    shape : (h, w) | (h, w, c)
+    streams : number of independent streams stepped per call
+    blur : None | (kw, kh, sigma_x[, sigma_y])   -- Gaussian, REFLECT_101
+    detector : 'MOG2' | 'FD'
+    morph : list of (op, kernel) with op in {'erode', 'dilate'} and kernel a
+        (kh, kw) array (non-zero = member)
+    """
+
+    def __init__(self, shape, streams=1, blur=(3, 3, 4.0), detector="MOG2", fd_threshold=5,
+                 morph=(("erode", np.ones((5, 5), np.uint8)), ("dilate", np.ones((5, 5), np.uint8))),
+                 mog2_params=None, device=None, ctx=None):
+        if len(shape) == 2:
+            h, w, c = shape[0], shape[1], 1
+        else:
+            h, w, c = shape
+        self.h, self.w, self.c, self.streams = int(h), int(w), int(c), int(streams)
+        lib = _lib.load()
+        d = _lib.PipelineDesc()
+        d.streams, d.h, d.w, d.c = self.streams, self.h, self.w, self.c
+        if blur is None:
+            d.blur = _lib.BLUR_NONE
+        else:
+            d.blur = _lib.BLUR_GAUSS
+            d.blur_kw, d.blur_kh = int(blur[0]), int(blur[1])
+            d.blur_sigma_x = float(blur[2])
+            d.blur_sigma_y = float(blur[3]) if len(blur) > 3 else 0.0
+        if detector == "MOG2":
+            d.detector = _lib.DET_MOG2
+        elif detector == "FD":
+            d.detector = _lib.DET_FD
+        else:
+            raise ValueError("Unknown method for foreground detection")
+        if mog2_params is None:
+            lib.gof_mog2_default_params(C.byref(d.mog2))
+        else:
+            d.mog2 = mog2_params
+        d.fd_threshold = float(fd_threshold)
+        morph = list(morph or [])
+        if len(morph) > _lib.MAX_MORPH:
+            raise ValueError("at most %d morphology operators" % _lib.MAX_MORPH)
+        d.n_morph = len(morph)
+        keep = []
+        for i, (op, kernel) in enumerate(morph):
+            k = np.ascontiguousarray(np.asarray(kernel) != 0, dtype=np.uint8)
+            if k.ndim != 2:
+                raise ValueError("kernel must be 2-D")
+            keep.append(k)
+            d.morph[i].op = _lib.ERODE if op == "erode" else _lib.DILATE
+            if op not in ("erode", "dilate"):
+                raise ValueError("unknown morphology operator %r" % (op,))
+            d.morph[i].kh, d.morph[i].kw = k.shape
+            d.morph[i].kernel = _lib.p8(k)
+        self._ctx = ctx if ctx is not None else _lib.default_context(device)
+        self._h = C.c_void_p()
+        _lib.check(lib.gof_pipeline_create(self._ctx.handle, C.byref(d), C.byref(self._h)))
+        del keep  # the library copied the structuring elements
+
+    # -- host buffers (what GOFPID.detect hands over) ------------------------
+    def apply(self, frames):
+        """frames: (h,w[,c]) for streams == 1, else (streams,h,w[,c]); -> uint8 mask(s)."""
+        x = _lib.as_u8(frames, "frames")
+        single = self.streams == 1 and x.ndim <= 3 and x.shape[:2] == (self.h, self.w)
+        want = (self.streams, self.h, self.w, self.c)
+        if x.size != int(np.prod(want)):
+            raise ValueError("Input shape has changed.")
+        out = np.empty((self.streams, self.h, self.w), np.uint8)
+        _lib.check(_lib.load().gof_pipeline_apply_host(self._h, _lib.p8(x), _lib.p8(out)))
+        return out[0] if single else out
+
+    # -- device buffers (bench / serving loop) -------------------------------
+    def apply_device(self, frames_ptr, masks_ptr, stream=None):
+        """Enqueue one step on device pointers (ints); does not synchronise."""
+        _lib.check(_lib.load().gof_pipeline_apply_dev(self._h, C.c_void_p(frames_ptr),
+                                                      C.c_void_p(masks_ptr),
+                                                      C.c_void_p(stream) if stream else None))
+
+    @property
+    def stream(self):
+        return self._ctx.stream
+
+    def synchronize(self):
+        self._ctx.synchronize()
+
+    def mean_modes(self):
+        v = C.c_double()
+        _lib.check(_lib.load().gof_pipeline_mean_modes(self._h, C.byref(v)))
+        return v.value
+
+    def algorithmic_bytes(self, mean_modes):
+        """(total, detector-kernel) algorithmic HBM bytes of one step."""
+        t, k = C.c_double(), C.c_double()
+        _lib.check(_lib.load().gof_pipeline_algorithmic_bytes(self._h, float(mean_modes),
+                                                              C.byref(t), C.byref(k)))
+        return t.value, k.value
+
+    def mog2_state(self):
+        """Export the model planes (host copies) -- parity tests / checkpoint."""
+        m = _lib.load().gof_pipeline_mog2(self._h)
+        if not m:
+            raise RuntimeError("not a MOG2 pipeline")
+        n, K, c = self.streams * self.h * self.w, 5, self.c
+        wt, var = np.empty((K, n), np.float32), np.empty((K, n), np.float32)
+        mean, modes = np.empty((K, c, n), np.float32), np.empty(n, np.uint8)
+        f32 = C.POINTER(C.c_float)
+        _lib.check(_lib.load().gof_mog2_export(m, wt.ctypes.data_as(f32), var.ctypes.data_as(f32),
+                                               mean.ctypes.data_as(f32), _lib.p8(modes)))
+        return {"weight": wt, "var": var, "mean": mean, "modes": modes,
+                "nframes": _lib.load().gof_mog2_nframes(m)}
+
+    def mog2_device_state(self):
+        """(device pointer, bytes) of the whole model: one buffer, RCCL-broadcastable."""
+        m = _lib.load().gof_pipeline_mog2(self._h)
+        if not m:
+            raise RuntimeError("not a MOG2 pipeline")
+        p, n = C.c_void_p(), C.c_size_t()
+        _lib.check(_lib.load().gof_mog2_device_state(m, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def set_nframes(self, nframes):
+        m = _lib.load().gof_pipeline_mog2(self._h)
+        if m:
+            _lib.check(_lib.load().gof_mog2_set_nframes(m, int(nframes)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.load().gof_pipeline_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,336 @@
+"""GPU parity tests (run on a real MI355X through gpurun): every HIP entry point,
+called through the C ABI, against the CPU oracle on the same seeded inputs.
+
+Bar: bit-exact.  Blur / FD / morphology are integer; MOG2 is float32 and the
+north star allows 1 ULP on the variance update, but the kernels are built with
+FP contraction off and IEEE division, so masks AND model state are compared
+for exact equality (tolerance 0).  PARITY UNPINNED vs cv2 itself: see
+tests/test_oracle.py.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from pygofpid_amd.synth import Clip, uniform_noise_frames
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def cv():
+    from pygofpid_amd import cv as _cv
+    return _cv
+
+
+def _rng(seed=17):
+    return np.random.default_rng(seed)
+
+
+# ---- step 1: Gaussian blur ------------------------------------------------
+
+BLUR_SHAPES = [(64, 50), (64, 32, 1), (32, 20, 3), (1, 1), (1, 9, 3), (9, 1), (2, 2, 3), (5, 3, 4),
+               (37, 129, 3), (70, 200, 3), (33, 65)]
+
+
+@pytest.mark.parametrize("shape", BLUR_SHAPES)
+@pytest.mark.parametrize("ks", [((3, 3), 4.0), ((5, 5), 4.0), ((7, 3), 1.5), ((3, 3), 0.0),
+                                ((1, 1), 2.0), ((9, 9), 0.0), ((31, 31), 6.0)])
+def test_gaussian_blur(cv, oracle, shape, ks):
+    x = _rng().integers(0, 255, shape, dtype=np.uint8)
+    (kw, kh), sigma = ks
+    got = cv.GaussianBlur(x, (kw, kh), sigma)
+    want = oracle.gaussian_blur(x, (kw, kh), sigma)
+    assert got.shape == want.shape and got.dtype == np.uint8
+    assert np.array_equal(got, want)
+
+
+def test_gaussian_blur_reference_call_convention(cv, oracle):
+    """blur['fun'](X, ksize, borderType): BORDER_DEFAULT lands in sigmaX
+    (pipeline.py:463-467)."""
+    x = _rng(1).integers(0, 255, (48, 64, 3), dtype=np.uint8)
+    keep = x.copy()
+    got = cv.GaussianBlur(x, (3, 3), cv.BORDER_DEFAULT)
+    assert np.array_equal(got, oracle.gaussian_blur(x, (3, 3), 4.0))
+    assert np.array_equal(x, keep)                       # input not mutated
+    assert cv.GaussianBlur(x[:, :, :1], (3, 3), 4).shape == (48, 64)   # (H,W,1) -> (H,W)
+    with pytest.raises(ValueError):
+        cv.GaussianBlur(x, (4, 4), 1.0)
+    with pytest.raises(ValueError):
+        cv.GaussianBlur(x.astype(np.float32), (3, 3), 1.0)
+
+
+def test_gaussian_blur_full_hd(cv, oracle):
+    x = _rng(2).integers(0, 255, (1080, 1920, 3), dtype=np.uint8)
+    assert np.array_equal(cv.GaussianBlur(x, (3, 3), 4), oracle.gaussian_blur(x, (3, 3), 4.0))
+    # size-independent property: a constant image is a fixed point
+    c = np.full((1080, 1920, 3), 201, np.uint8)
+    assert (cv.GaussianBlur(c, (5, 5), 4) == 201).all()
+
+
+# ---- step 3: morphology ---------------------------------------------------
+
+def _kernels(rng):
+    return [np.ones((5, 5), np.uint8), np.ones((7, 7), np.uint8), np.ones((3, 7), np.uint8),
+            np.ones((1, 1), np.uint8), np.ones((4, 4), np.uint8), np.ones((2, 5), np.uint8),
+            (rng.random((5, 5)) > 0.5).astype(np.uint8), (rng.random((4, 6)) > 0.4).astype(np.uint8),
+            np.array([[0, 1, 0], [1, 1, 1], [0, 1, 0]], np.uint8), np.ones((31, 31), np.uint8),
+            np.ones((15, 3), np.uint8)]
+
+
+@pytest.mark.parametrize("shape", [(64, 50), (20, 32), (1, 1), (3, 70), (70, 3), (100, 150),
+                                   (33, 129), (64, 64)])
+def test_erode_dilate(cv, oracle, shape):
+    rng = _rng(5)
+    m = rng.choice([0, 127, 255], size=shape).astype(np.uint8)
+    g = rng.integers(0, 256, size=shape).astype(np.uint8)   # arbitrary grey levels too
+    for k in _kernels(rng):
+        for src in (m, g):
+            assert np.array_equal(cv.erode(src, k), oracle.erode(src, k)), k.shape
+            assert np.array_equal(cv.dilate(src, k), oracle.dilate(src, k)), k.shape
+
+
+def test_morph_known_answers_and_properties(cv):
+    k5 = cv.getStructuringElement(cv.MORPH_RECT, (5, 5))
+    full = np.full((1080, 1920), 255, np.uint8)
+    assert (cv.erode(full, k5) == 255).all()                    # border never wins
+    one = np.zeros((1080, 1920), np.uint8)
+    one[500, 900] = 255
+    d = cv.dilate(one, k5)
+    assert int(d.sum()) == 25 * 255 and (d[498:503, 898:903] == 255).all()
+    assert np.array_equal(cv.erode(d, k5), one)
+    # idempotence of opening at full size
+    m = (_rng(9).random((1080, 1920)) > 0.7).astype(np.uint8) * 255
+    o1 = cv.dilate(cv.erode(m, k5), k5)
+    o2 = cv.dilate(cv.erode(o1, k5), k5)
+    assert np.array_equal(o1, o2)
+    assert (o1 <= m).all()                                      # opening is anti-extensive
+    with pytest.raises(ValueError):
+        cv.erode(np.zeros((4, 4, 3), np.uint8), k5)
+    with pytest.raises(ValueError):
+        cv.erode(m, np.ones((33, 33), np.uint8))
+
+
+# ---- step 2b: frame differencing ------------------------------------------
+
+@pytest.mark.parametrize("size", [(64, 50), (50, 64, 1), (32, 28, 3), (7, 5, 4), (300, 500, 3)])
+def test_framedifferencing(oracle, size):
+    """Reference test (tests/test_segmentation.py:12-24) + value parity."""
+    from pygofpid_amd.segmentation import FrameDifferencing, ForegroundEstimator
+    np.random.seed(17)
+    fd = FrameDifferencing(threshold=7.5)
+    ref = oracle.FrameDifferencing(threshold=7.5)
+    assert isinstance(fd, ForegroundEstimator) and fd.FOREGROUND == 255 and fd.BACKGROUND == 0
+    img = np.random.randint(0, high=255, size=size, dtype=np.uint8)
+    out = fd.apply(img)
+    ref.apply(img)
+    assert np.array_equal(out, np.zeros(size[:2]))
+    for i in range(4):
+        if i == 2:   # small differences straddling the threshold
+            img = (img.astype(np.int16) + np.random.randint(-9, 10, size=size)).clip(0, 255).astype(np.uint8)
+        else:
+            img = np.random.randint(0, high=255, size=size, dtype=np.uint8)
+        out = fd.apply(img)
+        assert out.shape == size[:2]
+        assert np.array_equal(out, ref.apply(img))
+    with pytest.raises(ValueError):
+        fd.apply(np.zeros((3, 3), np.uint8))
+
+
+def test_fd_golden():
+    from pygofpid_amd.segmentation import FrameDifferencing
+    g = np.load(os.path.join(GOLDEN, "fd_bgr.npz"))
+    fd = FrameDifferencing(7.5)
+    for f, want in zip(g["frames"], g["masks"]):
+        assert np.array_equal(fd.apply(f), want)
+
+
+# ---- step 2a: MOG2 ---------------------------------------------------------
+
+def _assert_state_equal(got, want):
+    live = np.arange(5)[:, None] < want["modes"][None, :]
+    assert np.array_equal(got["modes"], want["modes"])
+    assert np.array_equal(got["weight"][live], want["weight"][live])
+    assert np.array_equal(got["var"][live], want["var"][live])
+    for ch in range(want["mean"].shape[1]):
+        assert np.array_equal(got["mean"][:, ch][live], want["mean"][:, ch][live])
+
+
+@pytest.mark.parametrize("shape", [(32, 20), (20, 32, 1), (32, 20, 3), (6, 5, 4), (1, 1, 3),
+                                   (67, 131, 3)])
+def test_mog2_uniform_noise(cv, oracle, shape):
+    """Reference-test style input (tests/test_pipeline.py:98-109): worst case, no
+    mode ever fits, 5 modes per pixel."""
+    gpu, ref = cv.createBackgroundSubtractorMOG2(), oracle.MOG2()
+    for f in uniform_noise_frames(shape, 12, seed=3):
+        got, want = gpu.apply(f), ref.apply(f)
+        assert got.shape == tuple(shape[:2])
+        assert np.array_equal(got, want)
+    _assert_state_equal(gpu.export_state(), ref.export())
+
+
+@pytest.mark.parametrize("c", [1, 3])
+def test_mog2_clip_masks_and_state(cv, oracle, c):
+    """Static background + noise + moving objects + shadows: fit, prune, sort,
+    new-mode and shadow branches; state compared bit for bit after 120 frames."""
+    clip = Clip(72, 100, c, seed=17, n_objects=4)
+    gpu, ref = cv.createBackgroundSubtractorMOG2(), oracle.MOG2()
+    seen = set()
+    for t in range(120):
+        f = oracle.gaussian_blur(clip.frame(t))
+        got, want = gpu.apply(f), ref.apply(f)
+        assert np.array_equal(got, want), "frame %d: %d px differ" % (t, (got != want).sum())
+        seen |= set(np.unique(got).tolist())
+    assert seen == {0, 127, 255}
+    st = ref.export()
+    assert len(np.unique(st["modes"])) >= 3
+    _assert_state_equal(gpu.export_state(), st)
+
+
+def test_mog2_known_answers(cv):
+    x = np.array([[[10, 20, 30], [0, 0, 0], [255, 1, 0]]], np.uint8)
+    m = cv.createBackgroundSubtractorMOG2()
+    assert m.apply(x).tolist() == [[127, 255, 127]]
+    x2 = x.copy()
+    x2[0, 2] = [0, 200, 200]
+    assert m.apply(x2)[0, 0] == 0
+    st = m.export_state()
+    assert st["modes"].tolist() == [1, 1, 2] and st["nframes"] == 2
+    assert np.allclose(st["weight"][:2, 2], [0.75, 0.25])
+
+
+def test_mog2_golden_gray():
+    from pygofpid_amd import cv
+    g = np.load(os.path.join(GOLDEN, "mog2_gray_noise.npz"))
+    m = cv.createBackgroundSubtractorMOG2()
+    for f, want in zip(g["frames"], g["masks"]):
+        assert np.array_equal(m.apply(f), want)
+
+
+def test_mog2_state_roundtrip(cv, oracle):
+    """export -> import into a fresh model -> identical continuation
+    (checkpoint / warm start path)."""
+    clip = Clip(40, 48, 3, seed=2)
+    a = cv.createBackgroundSubtractorMOG2()
+    for t in range(20):
+        a.apply(clip.frame(t))
+    st = a.export_state()
+    b = cv.createBackgroundSubtractorMOG2()
+    b.import_state(st, (40, 48, 3))
+    for t in range(20, 30):
+        f = clip.frame(t)
+        assert np.array_equal(a.apply(f), b.apply(f))
+
+
+# ---- steps 1-3 fused -------------------------------------------------------
+
+def _run_pair(gpu, ref, frames):
+    for t, f in enumerate(frames):
+        got, want = gpu.apply(f), ref.apply(f)
+        assert np.array_equal(got, want), "frame %d: %d px differ" % (t, (got != want).sum())
+
+
+@pytest.mark.parametrize("shape", [(40, 56, 3), (64, 50, 1), (33, 67, 3), (130, 200, 3), (5, 4, 3)])
+def test_pipeline_default(oracle, shape):
+    from pygofpid_amd.foreground import ForegroundPipeline
+    h, w, c = shape
+    gpu = ForegroundPipeline(shape)
+    ref = oracle.Pipeline(h, w, c)
+    _run_pair(gpu, ref, Clip(h, w, c, seed=17, n_objects=3).frames(40))
+    assert abs(gpu.mean_modes() - ref.mean_modes()) < 1e-12
+
+
+def test_pipeline_golden():
+    from pygofpid_amd.foreground import ForegroundPipeline
+    g = np.load(os.path.join(GOLDEN, "pipeline_mog2_bgr.npz"))
+    gpu = ForegroundPipeline(g["frames"].shape[1:])
+    for f, want in zip(g["frames"], g["final_mask"]):
+        assert np.array_equal(gpu.apply(f), want)
+    st = gpu.mog2_state()
+    _assert_state_equal(st, {k: g[k] for k in ("weight", "var", "mean", "modes")})
+
+
+def test_pipeline_open_close_7x7(oracle):
+    """BASELINE config 3's operator list: [erode, dilate, dilate, erode] 7x7."""
+    from pygofpid_amd.foreground import ForegroundPipeline
+    k7 = np.ones((7, 7), np.uint8)
+    morph = [("erode", k7), ("dilate", k7), ("dilate", k7), ("erode", k7)]
+    gpu = ForegroundPipeline((90, 120, 3), morph=morph)
+    ref = oracle.Pipeline(90, 120, 3, morph=(("erode", 7), ("dilate", 7), ("dilate", 7), ("erode", 7)))
+    _run_pair(gpu, ref, Clip(90, 120, 3, seed=5).frames(25))
+
+
+@pytest.mark.parametrize("blur", [None, (5, 5, 4.0), (3, 3, 0.0)])
+def test_pipeline_other_blurs(oracle, blur):
+    from pygofpid_amd.foreground import ForegroundPipeline
+    gpu = ForegroundPipeline((50, 70, 3), blur=blur)
+    ref = oracle.Pipeline(50, 70, 3, blur_k=0 if blur is None else blur[0],
+                          blur_sigma=0.0 if blur is None else blur[2])
+    _run_pair(gpu, ref, Clip(50, 70, 3, seed=6).frames(20))
+
+
+def test_pipeline_nonrect_morph(oracle, cv):
+    from pygofpid_amd.foreground import ForegroundPipeline
+    cross = cv.getStructuringElement(cv.MORPH_CROSS, (5, 5))
+    gpu = ForegroundPipeline((50, 70, 3), morph=[("erode", cross), ("dilate", np.ones((4, 4), np.uint8))])
+    mog2 = oracle.MOG2()
+    for f in Clip(50, 70, 3, seed=7).frames(15):
+        want = oracle.dilate(oracle.erode(mog2.apply(oracle.gaussian_blur(f)), cross),
+                             np.ones((4, 4), np.uint8))
+        assert np.array_equal(gpu.apply(f), want)
+
+
+def test_pipeline_fd(oracle):
+    from pygofpid_amd.foreground import ForegroundPipeline
+    gpu = ForegroundPipeline((60, 80, 3), detector="FD", fd_threshold=7.5)
+    ref = oracle.Pipeline(60, 80, 3, detector="FD", fd_thr=7.5)
+    _run_pair(gpu, ref, Clip(60, 80, 3, seed=8).frames(10))
+
+
+def test_pipeline_streams_are_independent(oracle):
+    """A batch of S streams == S single-stream pipelines (the sharding unit)."""
+    from pygofpid_amd.foreground import ForegroundPipeline
+    S, h, w, c = 3, 44, 60, 3
+    clips = [Clip(h, w, c, seed=20 + s, n_objects=2 + s) for s in range(S)]
+    gpu = ForegroundPipeline((h, w, c), streams=S)
+    refs = [oracle.Pipeline(h, w, c) for _ in range(S)]
+    for t in range(25):
+        frames = np.stack([cl.frame(t) for cl in clips])
+        got = gpu.apply(frames)
+        assert got.shape == (S, h, w)
+        for s in range(S):
+            assert np.array_equal(got[s], refs[s].apply(frames[s]))
+
+
+def test_pipeline_full_hd_bit_exact(oracle):
+    """BASELINE config 2 geometry, a few frames against the oracle."""
+    from pygofpid_amd.foreground import ForegroundPipeline
+    h, w, c = 1080, 1920, 3
+    gpu = ForegroundPipeline((h, w, c))
+    ref = oracle.Pipeline(h, w, c)
+    _run_pair(gpu, ref, Clip(h, w, c, seed=17).frames(6))
+
+
+def test_pipeline_4k_open_close_bit_exact(oracle):
+    """BASELINE config 3 geometry."""
+    from pygofpid_amd.foreground import ForegroundPipeline
+    h, w, c = 2160, 3840, 3
+    k7 = np.ones((7, 7), np.uint8)
+    gpu = ForegroundPipeline((h, w, c), morph=[("erode", k7), ("dilate", k7), ("dilate", k7), ("erode", k7)])
+    ref = oracle.Pipeline(h, w, c, morph=(("erode", 7), ("dilate", 7), ("dilate", 7), ("erode", 7)))
+    _run_pair(gpu, ref, Clip(h, w, c, seed=3).frames(3))
+
+
+def test_pipeline_errors():
+    from pygofpid_amd.foreground import ForegroundPipeline
+    with pytest.raises(ValueError):
+        ForegroundPipeline((10, 10, 3), detector="blabla")      # tests/test_pipeline.py:112-118
+    with pytest.raises(ValueError):
+        ForegroundPipeline((10, 10, 2))
+    with pytest.raises(ValueError):
+        ForegroundPipeline((10, 10, 3), blur=(4, 4, 1.0))
+    p = ForegroundPipeline((10, 10, 3))
+    with pytest.raises(ValueError):
+        p.apply(np.zeros((12, 10, 3), np.uint8))                # tests/test_pipeline.py:31-41
