@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""Headline benchmark: frames/s of the per-frame foreground path at 1080p.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): 1920x1080 BGR frames, GaussianBlur 3x3
+(sigma 4, as the reference calls it) -> MOG2 -> erode 5x5 -> dilate 5x5, i.e.
+steps 1-3 of GOFPID.detect (pygofpid/pipeline.py:461-476).  One "step" is one
+pass of the path over one batch: one new frame for each of `--streams`
+independent video streams (8 by default, so that the background models,
+~0.4-1.7 GB in use, do not fit the 256 MiB Infinity Cache).  Frames are
+synthetic and already resident in HBM when the timed region starts.
+
+N > 1: one process per GPU (torch.distributed / RCCL only for the barrier and
+the MAX over ranks); every rank steps its own streams -- the path shards by
+stream with no data-path collective ("weak" scaling).
+
+Prints ONE JSON line on rank 0, including
+  roofline      -- dominant kernel (fused blur + MOG2): algorithmic bytes per
+                   launch / HIP-event time on the launch stream vs 8 TB/s
+  cpu_baseline  -- the CPU oracle ("port" of the OpenCV algorithms, NOT OpenCV)
+                   timed on this host's cores on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def make_pool(torch, streams, pool, h, w, device, seed):
+    """[pool][streams][h][w][3] uint8 on the device: BASELINE.md section 3 recipe
+    (gradient + texture background, N(0,2) noise, +60 rectangles moving 3 px per
+    frame with a 0.7x shadow patch beside each)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    yy = torch.arange(h, device=device, dtype=torch.float32)[:, None]
+    xx = torch.arange(w, device=device, dtype=torch.float32)[None, :]
+    grad = 60.0 + 100.0 * xx / max(1, w - 1) + 40.0 * yy / max(1, h - 1)
+    tint = torch.tensor([1.0, 0.92, 0.85], device=device)
+    frames = torch.empty((pool, streams, h, w, 3), dtype=torch.uint8, device=device)
+    oh, ow = max(4, h // 6), max(3, w // 16)
+    for s in range(streams):
+        tex = torch.randint(-12, 13, (h, w), generator=g, device=device).float()
+        bg = (grad + tex)[..., None] * tint
+        objs = []
+        for _ in range(6):
+            objs.append((int(torch.randint(0, w, (1,), generator=g, device=device)),
+                         int(torch.randint(0, max(1, h - oh), (1,), generator=g, device=device)),
+                         1 if float(torch.rand(1, generator=g, device=device)) < 0.5 else -1))
+        for t in range(pool):
+            f = bg.clone()
+            for (x0, y0, d) in objs:
+                x = (x0 + d * 3 * t) % w
+                f[y0:y0 + oh, min(w, x + ow):min(w, x + 2 * ow)] *= 0.7
+                f[y0:y0 + oh, x:min(w, x + ow)] += 60.0
+            f += torch.randn(f.shape, generator=g, device=device) * 2.0
+            frames[t, s] = f.round().clamp(0, 255).to(torch.uint8)
+    return frames
+
+
+def cpu_baseline(frames_host, h, w, budget_s):
+    """Time the CPU oracle on this host (checker reused as the baseline leg)."""
+    from oracle import cpu as oracle
+    oracle.build()
+    p = oracle.Pipeline(h, w, 3)
+    n = len(frames_host)
+    for i in range(min(8, n)):          # page in + first-frame model creation
+        p.apply(frames_host[i % n])
+    done, t0 = 0, time.perf_counter()
+    while True:
+        p.apply(frames_host[done % n])
+        done += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or done >= 2048:
+            break
+    return {"value": round(done / el, 2), "unit": "frames/s", "cores": p.threads, "kind": "port",
+            "sample": "%d frames of 1 stream %dx%d BGR in %.1f s, OpenMP row bands over %d threads; "
+                      "OpenCV-algorithm CPU restatement (oracle/gof_oracle.c), not OpenCV"
+                      % (done, w, h, el, p.threads),
+            "mean_modes": round(p.mean_modes(), 4)}
+
+
+def load_traffic(path, key):
+    """HBM bytes per launch from the committed PMC passes (profiles/), if the
+    recorded configuration matches this run; else None."""
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+        if rec.get("config") == key:
+            return rec.get("hbm_bytes_per_launch")
+    except Exception:
+        pass
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=256)
+    ap.add_argument("--warmup", type=int, default=64)
+    ap.add_argument("--streams", type=int, default=8, help="video streams stepped per GPU")
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--pool", type=int, default=32, help="distinct synthetic frames per stream")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="0 disables the CPU leg")
+    ap.add_argument("--traffic-file", default=os.path.join(ROOT, "profiles", "traffic_latest.json"))
+    ap.add_argument("--no-events", action="store_true",
+                    help="do not bracket kernels with HIP events (roofline block omitted)")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch N > 1 with torch.distributed.run (one process per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU fallback")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from pygofpid_amd import _lib
+    from pygofpid_amd.foreground import ForegroundPipeline
+
+    h, w, S, K, W = args.height, args.width, args.streams, args.steps, args.warmup
+    frames = make_pool(torch, S, args.pool, h, w, device, seed=17 + rank)
+    masks = torch.empty((S, h, w), dtype=torch.uint8, device=device)
+    torch.cuda.synchronize()
+
+    ctx = _lib.Context(local)
+    pipe = ForegroundPipeline((h, w, 3), streams=S, ctx=ctx)
+    P = args.pool
+
+    def barrier():
+        pipe.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for t in range(W):
+        pipe.apply_device(frames[t % P].data_ptr(), masks.data_ptr())
+    barrier()
+    mbar_start = pipe.mean_modes()
+    if not args.no_events:
+        pipe.profile(True, K)
+    barrier()
+    t0 = time.perf_counter()
+    for t in range(W, W + K):
+        pipe.apply_device(frames[t % P].data_ptr(), masks.data_ptr())
+    pipe.synchronize()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        el = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        elapsed = float(el.item())
+
+    det_ms = morph_ms = 0.0
+    n_meas = 0
+    if not args.no_events:
+        det_ms, morph_ms, n_meas = pipe.profile_query()
+        pipe.profile(False)
+    mbar_end = pipe.mean_modes()
+    mbar = 0.5 * (mbar_start + mbar_end)
+    fg = float((masks != 0).float().mean().item())
+
+    if rank == 0:
+        total_frames = S * K * world
+        out = {
+            "metric": "frames/sec at 1080p MOG2+5x5 morph",
+            "value": round(total_frames / elapsed, 1),
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": round(elapsed / K * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "%dx%d BGR uint8, GaussianBlur 3x3 (sigma 4) -> MOG2 (cv2 defaults, "
+                            "shadows on) -> erode 5x5 -> dilate 5x5; %d streams per GPU, one "
+                            "frame per stream per step; frames resident in HBM" % (w, h, S),
+                "streams_per_gpu": S, "frames_per_step": S * world, "height": h, "width": w,
+                "channels": 3, "mean_modes": round(mbar, 4), "foreground_fraction": round(fg, 5),
+                "parallelism": "streams sharded %d per GPU, no data-path collective" % S,
+            },
+        }
+        if n_meas:
+            total_b, det_b = pipe.algorithmic_bytes(mbar)
+            det_s = det_ms / n_meas * 1e-3
+            achieved = det_b / det_s / 1e9
+            key = {"streams": S, "height": h, "width": w}
+            out["roofline"] = {
+                "bound": "hbm",
+                "kernel": "mog2_kernel<3,true> (fused 3x3 blur + MOG2 update + classify)",
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": load_traffic(args.traffic_file, key),
+                "algorithmic_bytes_per_launch": int(det_b),
+                "bytes_per_pixel": round(det_b / (S * h * w), 3),
+                "avg_kernel_us": round(det_s * 1e6, 2),
+                "morph_kernel_us": round(morph_ms / n_meas * 1e3, 2),
+                "launches_timed": n_meas,
+                "whole_step_GBps": round(total_b / (elapsed / K) / 1e9, 1),
+            }
+        if args.cpu_seconds > 0:
+            host = [frames[i, 0].cpu().numpy() for i in range(P)]
+            out["cpu_baseline"] = cpu_baseline(host, h, w, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -167,6 +167,16 @@ int gof_pipeline_mean_modes(gof_pipeline *p, double *mean_modes);
 int gof_pipeline_algorithmic_bytes(gof_pipeline *p, double mean_modes, double *total_bytes,
                                    double *detector_bytes);
 
+/* Per-kernel timing with HIP events on the launch stream (what bench.py's
+ * roofline block is computed from).  enable != 0: every following apply
+ * brackets its detector kernel (fused blur + MOG2, or FD) and its morphology
+ * kernel(s) with event pairs (at most `capacity` applies are kept).  The query
+ * synchronises the recorded events and returns the SUM of elapsed ms and the
+ * number of applies measured, then clears the record. */
+int gof_pipeline_profile_enable(gof_pipeline *p, int enable, int capacity);
+int gof_pipeline_profile_query(gof_pipeline *p, double *detector_ms, double *morph_ms,
+                               int *n_applies);
+
 #ifdef __cplusplus
 }
 #endif

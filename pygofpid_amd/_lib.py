@@ -94,6 +94,9 @@ SIGNATURES = {
     "gof_pipeline_mean_modes": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "gof_pipeline_algorithmic_bytes": (C.c_int, [C.c_void_p, C.c_double, C.POINTER(C.c_double),
                                                  C.POINTER(C.c_double)]),
+    "gof_pipeline_profile_enable": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "gof_pipeline_profile_query": (C.c_int, [C.c_void_p, C.POINTER(C.c_double),
+                                             C.POINTER(C.c_double), C.POINTER(C.c_int)]),
 }
 
 _lib = None

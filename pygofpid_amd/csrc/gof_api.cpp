@@ -115,6 +115,10 @@ struct gof_pipeline {
     gof_fd *fd = nullptr;
     DevBuf in, out, blurred, m0, m1;
     unsigned long long *d_sum = nullptr;
+    // profiling: events[3*i+0..2] = before detector, after detector, after morphology
+    bool prof = false;
+    std::vector<hipEvent_t> events;
+    size_t prof_used = 0;
 };
 
 namespace {
@@ -783,6 +787,8 @@ void gof_pipeline_destroy(gof_pipeline *p)
     p->m1.release();
     if (p->d_sum)
         (void)hipFree(p->d_sum);
+    for (hipEvent_t e : p->events)
+        (void)hipEventDestroy(e);
     delete p;
 }
 
@@ -807,6 +813,11 @@ int gof_pipeline_apply_dev(gof_pipeline *p, const void *d_frames, void *d_masks,
         x = (const uint8_t *)p->blurred.p;
     }
 
+    const bool prof = p->prof && 3 * (p->prof_used + 1) <= p->events.size();
+    hipEvent_t *ev = prof ? &p->events[3 * p->prof_used] : nullptr;
+    if (prof)
+        GOF_HIP(hipEventRecord(ev[0], s));
+
     // step 2 (pipeline.py:470)
     uint8_t *det_out = (uint8_t *)d_masks;
     if (d.n_morph > 0) {
@@ -827,6 +838,9 @@ int gof_pipeline_apply_dev(gof_pipeline *p, const void *d_frames, void *d_masks,
             return rc;
     }
 
+    if (prof)
+        GOF_HIP(hipEventRecord(ev[1], s));
+
     // step 3 (pipeline.py:473-475)
     if (d.n_morph > 0) {
         if (p->chain_ok) {
@@ -846,6 +860,10 @@ int gof_pipeline_apply_dev(gof_pipeline *p, const void *d_frames, void *d_masks,
             }
         }
     }
+    if (prof) {
+        GOF_HIP(hipEventRecord(ev[2], s));
+        p->prof_used++;
+    }
     return GOF_OK;
 }
 
@@ -864,6 +882,43 @@ int gof_pipeline_apply_host(gof_pipeline *p, const uint8_t *frames, uint8_t *mas
         return rc;
     GOF_HIP(hipMemcpyAsync(masks, p->out.p, npx, hipMemcpyDeviceToHost, s));
     GOF_HIP(hipStreamSynchronize(s));
+    return GOF_OK;
+}
+
+int gof_pipeline_profile_enable(gof_pipeline *p, int enable, int capacity)
+{
+    if (!p || capacity < 0 || capacity > (1 << 20))
+        return fail(GOF_EINVAL, "bad argument");
+    GOF_HIP(hipSetDevice(p->ctx->device));
+    p->prof = enable != 0;
+    p->prof_used = 0;
+    while (p->prof && p->events.size() < 3 * (size_t)capacity) {
+        hipEvent_t e;
+        GOF_HIP(hipEventCreate(&e));
+        p->events.push_back(e);
+    }
+    return GOF_OK;
+}
+
+int gof_pipeline_profile_query(gof_pipeline *p, double *detector_ms, double *morph_ms,
+                               int *n_applies)
+{
+    if (!p || !detector_ms || !morph_ms || !n_applies)
+        return fail(GOF_EINVAL, "NULL argument");
+    GOF_HIP(hipSetDevice(p->ctx->device));
+    double a = 0, b = 0;
+    for (size_t i = 0; i < p->prof_used; i++) {
+        float ms = 0;
+        GOF_HIP(hipEventSynchronize(p->events[3 * i + 2]));
+        GOF_HIP(hipEventElapsedTime(&ms, p->events[3 * i], p->events[3 * i + 1]));
+        a += ms;
+        GOF_HIP(hipEventElapsedTime(&ms, p->events[3 * i + 1], p->events[3 * i + 2]));
+        b += ms;
+    }
+    *detector_ms = a;
+    *morph_ms = b;
+    *n_applies = (int)p->prof_used;
+    p->prof_used = 0;
     return GOF_OK;
 }
 

@@ -17,11 +17,14 @@ namespace {
 
 __device__ __forceinline__ int reflect101(int p, int len)
 {
+    // cv::borderInterpolate(BORDER_REFLECT_101) in closed form: period 2*len-2
     if (len == 1)
         return 0;
-    while (p < 0 || p >= len)
-        p = p < 0 ? -p : 2 * len - 2 - p;
-    return p;
+    const int period = 2 * len - 2;
+    p %= period;
+    if (p < 0)
+        p += period;
+    return p < len ? p : period - p;
 }
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -359,10 +362,8 @@ __global__ __launch_bounds__(256) void blur_kernel(const uint8_t *__restrict__ s
 
     for (int idx = threadIdx.x; idx < inH * inW; idx += 256) {
         int r = idx / inW, col = idx - r * inW;
-        int gy = reflect101(clampi(y0 - ry + r, -H, 2 * H - 1), H);
-        int gx = reflect101(clampi(x0 - rx + col, -W, 2 * W - 1), W);
-        gy = clampi(gy, 0, H - 1);
-        gx = clampi(gx, 0, W - 1);
+        int gy = reflect101(y0 - ry + r, H);
+        int gx = reflect101(x0 - rx + col, W);
         const uint8_t *p = simg + ((size_t)gy * W + gx) * C;
 #pragma unroll
         for (int c = 0; c < C; c++)

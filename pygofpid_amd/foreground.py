@@ -112,6 +112,18 @@ class ForegroundPipeline:
                                                               C.byref(t), C.byref(k)))
         return t.value, k.value
 
+    def profile(self, enable, capacity=0):
+        """Bracket each step's kernels with HIP events on the launch stream."""
+        _lib.check(_lib.load().gof_pipeline_profile_enable(self._h, int(bool(enable)),
+                                                           int(capacity)))
+
+    def profile_query(self):
+        """-> (sum detector-kernel ms, sum morphology-kernel ms, steps measured)"""
+        a, b, n = C.c_double(), C.c_double(), C.c_int()
+        _lib.check(_lib.load().gof_pipeline_profile_query(self._h, C.byref(a), C.byref(b),
+                                                          C.byref(n)))
+        return a.value, b.value, n.value
+
     def mog2_state(self):
         """Export the model planes (host copies) -- parity tests / checkpoint."""
         m = _lib.load().gof_pipeline_mog2(self._h)
