@@ -23,6 +23,38 @@ def build(force=False):
     return _SO
 
 
+
+
+def cpu_budget():
+    """CPUs this process may actually use: min(affinity mask, cgroup CPU quota).
+    A GPU box exposes all host cores but grants a share; OpenMP would otherwise
+    start one spinning thread per visible core."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(int(parts[0]) / int(parts[1]))))
+            else:
+                q = int(parts[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                        n = min(n, max(1, q // int(f.read())))
+        except (OSError, ValueError, IndexError):
+            pass
+    return max(1, n)
+
+
+# libgomp reads these once, when the library is loaded
+os.environ.setdefault("OMP_NUM_THREADS", str(cpu_budget()))
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
 _lib = None
 
 _u8p = C.POINTER(C.c_uint8)

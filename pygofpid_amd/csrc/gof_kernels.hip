@@ -217,6 +217,16 @@ __device__ __forceinline__ uint8_t mog2_update(PixelModel<C> &M, int &nmodes_io,
     return shadow ? (uint8_t)k.shadow_value : (uint8_t)255;
 }
 
+// REFLECT_101 for a reach of one pixel: -1 -> 1, len -> len-2 (len == 1 -> 0)
+__device__ __forceinline__ int reflect1(int p, int len)
+{
+    if (p < 0)
+        return len > 1 ? 1 : 0;
+    if (p >= len)
+        return len > 1 ? len - 2 : 0;
+    return p;
+}
+
 template <int C, bool BLUR3>
 __global__ __launch_bounds__(256) void mog2_kernel(const uint8_t *__restrict__ frame,
                                                    uint8_t *__restrict__ mask,
@@ -226,77 +236,96 @@ __global__ __launch_bounds__(256) void mog2_kernel(const uint8_t *__restrict__ f
                                                    uint32_t ky012)
 {
     constexpr int F = 2 + C;  // floats per mode
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    // wave-uniform values are forced into SGPRs: row index, row bases, plane bases
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
     const int img = blockIdx.z;
     const int x = x0 + lane, y = y0 + wave;
-    const bool valid = x < W && y < H;
     const size_t N = (size_t)H * W;
     const uint8_t *fimg = frame + (size_t)img * N * C;
 
-    // ---- stage the (TH+2) x (TW+2) px input tile, raw bytes, dword loads ----
-    constexpr int ROWD = ((TW + 2) * C + 3 + 3) / 4;  // dwords per staged row incl. misalignment
+    // ---- stage the (TH+2) x (TW+2) px input tile: raw bytes, aligned dword
+    //      loads, each wave stages rows {wave, wave+4}; borders are resolved
+    //      when the tile is read ----
+    // dwords per staged row: misalignment slack + one dword of read-ahead for px()
+    constexpr int ROWD = ((TW + 2) * C + 3 + 3) / 4 + 1;
     __shared__ uint32_t tile[BLUR3 ? (TH + 2) * ROWD : 1];
     const int sx0 = x0 > 0 ? x0 - 1 : 0;
     if (BLUR3) {
         const int sx1 = (x0 + TW + 1) < W ? (x0 + TW + 1) : W;
         const int nb = (sx1 - sx0) * C;
-        for (int idx = threadIdx.x; idx < (TH + 2) * ROWD; idx += 256) {
-            int r = idx / ROWD, d = idx - r * ROWD;
-            int gy = clampi(reflect101(y0 - 1 + r, H), 0, H - 1);
-            const uint8_t *a = fimg + ((size_t)gy * W + sx0) * C;
-            int mis = (int)((uintptr_t)a & 3);
-            int ndw = (mis + nb + 3) >> 2;
-            if (d < ndw)
-                tile[idx] = ((const uint32_t *)(a - mis))[d];
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++) {
+            const int r = wave + 4 * rr;
+            if (r < TH + 2) {
+                const int gy = clampi(reflect1(y0 - 1 + r, H), 0, H - 1);
+                const uint8_t *a = fimg + ((size_t)gy * W + sx0) * C;
+                const int mis = (int)((uintptr_t)a & 3);
+                const int ndw = (mis + nb + 3) >> 2;
+                for (int d = lane; d < ndw; d += 64)
+                    tile[r * ROWD + d] = ((const uint32_t *)(a - mis))[d];
+            }
         }
     }
 
-    // ---- issue the model loads early: mode count + mode 0 speculatively ----
-    const size_t gi = (size_t)img * N + (size_t)(valid ? y : 0) * W + (valid ? x : 0);
+    // ---- model: plane p of this wave's row starts at a wave-uniform address,
+    //      the lane only adds x; mode count + mode 0 are loaded speculatively ----
+    const bool rowok = y < H;
+    const int yy = rowok ? y : 0;
+    const bool valid = rowok && x < W;
+    const unsigned xl = valid ? (unsigned)x : 0u;           // lane offset within the row
+    const size_t rowoff = (size_t)img * N + (size_t)yy * W; // wave-uniform
+    float *const prow = planes + rowoff;
     PixelModel<C> M;
-    int nmodes = modes[gi];
-    {
-        const float *p = planes + gi;
-        M.w[0] = p[0];
-        M.var[0] = p[np];
+    int nmodes = modes[rowoff + xl];
+    M.w[0] = prow[xl];
+    M.var[0] = (prow + np)[xl];
 #pragma unroll
-        for (int c = 0; c < C; c++)
-            M.mu[0][c] = p[(size_t)(2 + c) * np];
-    }
+    for (int c = 0; c < C; c++)
+        M.mu[0][c] = (prow + (size_t)(2 + c) * np)[xl];
 
     float xin[C];
     if (BLUR3) {
         __syncthreads();
-        if (valid) {
-            const int kx[3] = {(int)(kx012 & 1023), (int)((kx012 >> 10) & 1023), (int)(kx012 >> 20)};
-            const int ky[3] = {(int)(ky012 & 1023), (int)((ky012 >> 10) & 1023), (int)(ky012 >> 20)};
-            const int pl = (reflect101(x - 1, W) - sx0) * C, pc = (x - sx0) * C,
-                      pr = (reflect101(x + 1, W) - sx0) * C;
-            uint32_t acc[C];
-#pragma unroll
-            for (int c = 0; c < C; c++)
-                acc[c] = 32768u;
-#pragma unroll
-            for (int j = 0; j < 3; j++) {
-                int r = wave + j;
-                int gy = clampi(reflect101(y0 - 1 + r, H), 0, H - 1);
-                int mis = (int)((uintptr_t)(fimg + ((size_t)gy * W + sx0) * C) & 3);
-                const uint8_t *row = (const uint8_t *)(tile + r * ROWD) + mis;
-#pragma unroll
-                for (int c = 0; c < C; c++) {
-                    uint32_t hsum = kx[0] * row[pl + c] + kx[1] * row[pc + c] + kx[2] * row[pr + c];
-                    acc[c] += ky[j] * hsum;
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < C; c++)
-                xin[c] = (float)(acc[c] >> 16);
-        }
-    } else {
+        const int kx0 = (int)(kx012 & 1023), kx1 = (int)((kx012 >> 10) & 1023), kx2 = (int)(kx012 >> 20);
+        const int ky[3] = {(int)(ky012 & 1023), (int)((ky012 >> 10) & 1023), (int)(ky012 >> 20)};
+        // byte offsets (within a staged row) of the left / centre / right pixel
+        const int xc = valid ? x : sx0;
+        const int pl = (reflect1(xc - 1, W) - sx0) * C, pc = (xc - sx0) * C,
+                  pr = (reflect1(xc + 1, W) - sx0) * C;
+        uint32_t acc[C];
 #pragma unroll
         for (int c = 0; c < C; c++)
-            xin[c] = (float)fimg[((size_t)(valid ? y : 0) * W + (valid ? x : 0)) * C + c];
+            acc[c] = 32768u;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const int r = wave + j;
+            const int gy = clampi(reflect1(y0 - 1 + r, H), 0, H - 1);
+            const int mis = (int)((uintptr_t)(fimg + ((size_t)gy * W + sx0) * C) & 3);
+            const uint32_t *row = tile + r * ROWD;
+            // C consecutive bytes starting at byte offset o of the staged row
+            auto px = [&](int o) -> uint32_t {
+                o += mis;
+                const uint32_t lo = row[o >> 2], hi = row[(o >> 2) + 1];
+                return __builtin_amdgcn_alignbyte(hi, lo, (unsigned)(o & 3));
+            };
+            const uint32_t L = px(pl), Cn = px(pc), R = px(pr);
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+                const uint32_t hsum = kx0 * ((L >> (8 * c)) & 255u) + kx1 * ((Cn >> (8 * c)) & 255u) +
+                                      kx2 * ((R >> (8 * c)) & 255u);
+                acc[c] += ky[j] * hsum;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < C; c++)
+            xin[c] = (float)(acc[c] >> 16);
+    } else {
+        const uint8_t *fp = fimg + ((size_t)yy * W + xl) * C;
+#pragma unroll
+        for (int c = 0; c < C; c++)
+            xin[c] = (float)fp[c];
     }
     if (!valid)
         return;
@@ -305,12 +334,12 @@ __global__ __launch_bounds__(256) void mog2_kernel(const uint8_t *__restrict__ f
 #pragma unroll
     for (int m = 1; m < kMaxModes; m++) {
         if (m < nmodes) {
-            const float *p = planes + (size_t)m * F * np + gi;
-            M.w[m] = p[0];
-            M.var[m] = p[np];
+            const float *pm = prow + (size_t)m * F * np;
+            M.w[m] = pm[xl];
+            M.var[m] = (pm + np)[xl];
 #pragma unroll
             for (int c = 0; c < C; c++)
-                M.mu[m][c] = p[(size_t)(2 + c) * np];
+                M.mu[m][c] = (pm + (size_t)(2 + c) * np)[xl];
         } else {
             M.w[m] = 0.f;
             M.var[m] = 0.f;
@@ -325,16 +354,16 @@ __global__ __launch_bounds__(256) void mog2_kernel(const uint8_t *__restrict__ f
 #pragma unroll
     for (int m = 0; m < kMaxModes; m++) {
         if (m < nmodes) {
-            float *p = planes + (size_t)m * F * np + gi;
-            p[0] = M.w[m];
-            p[np] = M.var[m];
+            float *pm = prow + (size_t)m * F * np;
+            pm[xl] = M.w[m];
+            (pm + np)[xl] = M.var[m];
 #pragma unroll
             for (int c = 0; c < C; c++)
-                p[(size_t)(2 + c) * np] = M.mu[m][c];
+                (pm + (size_t)(2 + c) * np)[xl] = M.mu[m][c];
         }
     }
-    modes[gi] = (uint8_t)nmodes;
-    mask[gi] = out;
+    modes[rowoff + xl] = (uint8_t)nmodes;
+    mask[rowoff + xl] = out;
 }
 
 // ---------------------------------------------------------------------------
@@ -490,77 +519,180 @@ __global__ __launch_bounds__(256) void morph_kernel(int op, const uint8_t *__res
 // ---------------------------------------------------------------------------
 // fused chain of rectangular erode/dilate ops (the reference default
 // [erode 5x5, dilate 5x5], pipeline.py:177-186): one HBM read and one write of
-// the mask, all intermediates in LDS.  Separable row-min / column-min per op.
-// Between ops, positions outside the image are forced to the NEXT op's identity
-// when they are read, which is exactly what cv2's constant border does to the
-// intermediate image.
+// the mask, all intermediates in LDS, 4 pixels per lane packed in a dword.
+//
+// Separable: per op a row pass (window 2*rx+1) A -> B and a column pass
+// (window 2*ry+1) B -> A.  A shifted window operand is one v_alignbyte of two
+// neighbouring LDS dwords; the byte-wise min/max runs as two v_pk_{min,max}_u16
+// on the even and odd bytes.  Out-of-image bytes hold the CURRENT op's identity
+// (255 for erode, 0 for dilate): written at staging time and re-written after
+// every op, which is what cv2's constant border does to each intermediate image.
+//
+// Tile = 128 x 32 output px; the halo is Q = sum(ceil(rx/4)) dwords per side
+// and RY = sum(ry) rows, so every op's compute range stays dword-granular.
 // ---------------------------------------------------------------------------
-constexpr int CTW = 64, CTH = 32;
+constexpr int CTWD = 32;   // output tile width in dwords (128 px)
+constexpr int CTH = 32;    // output tile height
+constexpr int CMAXQ = 4;   // per-op horizontal reach in dwords: rx <= 15
+constexpr int CMAXR = 15;  // per-op vertical radius
+
+typedef unsigned short gof_us2 __attribute__((ext_vector_type(2)));
+
+template <bool IS_MAX>
+__device__ __forceinline__ uint32_t pk16(uint32_t a, uint32_t b)
+{
+    gof_us2 x = __builtin_bit_cast(gof_us2, a), y = __builtin_bit_cast(gof_us2, b);
+    gof_us2 r = IS_MAX ? __builtin_elementwise_max(x, y) : __builtin_elementwise_min(x, y);
+    return __builtin_bit_cast(uint32_t, r);
+}
+
+// accumulate one packed-u8 operand into the split (even bytes, odd bytes) accumulators
+template <bool IS_MAX>
+__device__ __forceinline__ void acc_u8x4(uint32_t &ae, uint32_t &ao, uint32_t v)
+{
+    ae = pk16<IS_MAX>(ae, v & 0x00FF00FFu);
+    ao = pk16<IS_MAX>(ao, (v >> 8) & 0x00FF00FFu);
+}
+
+// bytes of the dword at (gy, gx0..gx0+3) that lie inside the image (gx0 % 4 == 0)
+__device__ __forceinline__ uint32_t in_image_mask(int gy, int gx0, int H, int W)
+{
+    if (gy < 0 || gy >= H || gx0 < 0 || gx0 >= W)
+        return 0u;
+    int nvalid = W - gx0;
+    return nvalid >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nvalid)) - 1u);
+}
+
+// Strided walk of a rows x cols index space by 256 threads without a division
+// per element: (r, c) advance by (256 / cols, 256 % cols) with one carry.
+struct Walk2D {
+    int r, c, dr, dc, cols;
+    __device__ __forceinline__ Walk2D(int cols_) : cols(cols_)
+    {
+        r = (int)threadIdx.x / cols;
+        c = (int)threadIdx.x - r * cols;
+        dr = 256 / cols;
+        dc = 256 - dr * cols;
+    }
+    __device__ __forceinline__ void next()
+    {
+        r += dr;
+        c += dc;
+        if (c >= cols) {
+            c -= cols;
+            r++;
+        }
+    }
+};
+
+template <bool IS_MAX>
+__device__ __forceinline__ void chain_op(uint32_t *A, uint32_t *B, int inWd, int inH, int c_lo,
+                                         int c_hi, int my, int rx, int ry, int X0, int Y0, int H,
+                                         int W, uint32_t next_ident)
+{
+    const uint32_t ident = IS_MAX ? 0u : 0x00FF00FFu;   // per 16-bit lane
+    const int cols = c_hi - c_lo;
+    // ---- row pass A -> B: rows [my, inH-my), dwords [c_lo, c_hi) ----
+    const int rows = inH - 2 * my;
+    for (Walk2D wk(cols); wk.r < rows; wk.next()) {
+        const int r = my + wk.r, cd = c_lo + wk.c;
+        const uint32_t *p = A + r * inWd + cd;
+        uint32_t ae = ident, ao = ident;
+#pragma unroll
+        for (int q = -CMAXQ; q <= CMAXQ; q++) {
+            if (4 * q + 3 < -rx || 4 * q > rx)   // wave-uniform
+                continue;
+            const uint32_t lo = p[q];
+            const uint32_t hi = (4 * q + 1 <= rx && q < CMAXQ) ? p[q + 1] : 0u;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const int sft = 4 * q + b;
+                if (sft < -rx || sft > rx)
+                    continue;
+                acc_u8x4<IS_MAX>(ae, ao, b == 0 ? lo : __builtin_amdgcn_alignbyte(hi, lo, b));
+            }
+        }
+        B[r * inWd + cd] = ae | (ao << 8);
+    }
+    __syncthreads();
+    // ---- column pass B -> A: rows [my+ry, inH-my-ry) ----
+    const int rows2 = inH - 2 * (my + ry);
+    for (Walk2D wk(cols); wk.r < rows2; wk.next()) {
+        const int r = my + ry + wk.r, cd = c_lo + wk.c;
+        const uint32_t *p = B + r * inWd + cd;
+        uint32_t ae = ident, ao = ident;
+#pragma unroll
+        for (int d = -CMAXR; d <= CMAXR; d++) {
+            if (d < -ry || d > ry)
+                continue;
+            acc_u8x4<IS_MAX>(ae, ao, p[d * inWd]);
+        }
+        uint32_t v = ae | (ao << 8);
+        const uint32_t m = in_image_mask(Y0 + r, X0 + 4 * cd, H, W);
+        A[r * inWd + cd] = (v & m) | (next_ident & ~m);
+    }
+    __syncthreads();
+}
 
 __global__ __launch_bounds__(256) void morph_chain_kernel(const uint8_t *__restrict__ src,
                                                           uint8_t *__restrict__ dst, int H, int W,
-                                                          RectChain ch, int RX, int RY)
+                                                          RectChain ch, int HQ, int RY, int fast)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int inW = CTW + 2 * RX, inH = CTH + 2 * RY;
-    uint8_t *A = smem;
-    uint8_t *B = smem + (((size_t)inW * inH + 15) & ~(size_t)15);
-    const int x0 = blockIdx.x * CTW - RX, y0 = blockIdx.y * CTH - RY;  // tile origin in image coords
+    const int inWd = CTWD + 2 * HQ, inH = CTH + 2 * RY;
+    uint32_t *A = (uint32_t *)smem;
+    uint32_t *B = A + inWd * inH;
+    const int X0 = blockIdx.x * (4 * CTWD) - 4 * HQ, Y0 = blockIdx.y * CTH - RY;
     const size_t N = (size_t)H * W;
     const uint8_t *simg = src + (size_t)blockIdx.z * N;
     uint8_t *dimg = dst + (size_t)blockIdx.z * N;
 
-    for (int idx = threadIdx.x; idx < inH * inW; idx += 256) {
-        int r = idx / inW, col = idx - r * inW;
-        int gy = y0 + r, gx = x0 + col;
-        uint8_t v = 0;
-        if (gy >= 0 && gy < H && gx >= 0 && gx < W)
-            v = simg[(size_t)gy * W + gx];
-        A[idx] = v;
+    const uint32_t ident0 = ch.op[0] ? 0u : 0xFFFFFFFFu;
+    for (Walk2D wk(inWd); wk.r < inH; wk.next()) {
+        const int r = wk.r, cd = wk.c, idx = r * inWd + cd;
+        const int gy = Y0 + r, gx0 = X0 + 4 * cd;
+        const uint32_t m = in_image_mask(gy, gx0, H, W);
+        uint32_t v = 0;
+        if (m) {
+            const uint8_t *p = simg + (size_t)gy * W + gx0;
+            if (fast) {
+                v = *(const uint32_t *)p;
+            } else {
+                const int nvalid = W - gx0 < 4 ? W - gx0 : 4;
+                for (int b = 0; b < nvalid; b++)
+                    v |= (uint32_t)p[b] << (8 * b);
+            }
+        }
+        A[idx] = (v & m) | (ident0 & ~m);
     }
     __syncthreads();
 
-    int mx = 0, my = 0;  // margin already consumed on each side
+    int c_lo = 0, my = 0;
     for (int o = 0; o < ch.n; o++) {
-        const int op = ch.op[o], rx = ch.rx[o], ry = ch.ry[o];
-        const int ident = op ? 0 : 255;
-        // row pass A -> B over rows [my, inH-my), cols [mx+rx, inW-mx-rx)
-        const int rows = inH - 2 * my, cols = inW - 2 * (mx + rx);
-        for (int idx = threadIdx.x; idx < rows * cols; idx += 256) {
-            int r = my + idx / cols, col = mx + rx + idx % cols;
-            int gy = y0 + r;
-            int v = ident;
-            if (gy >= 0 && gy < H) {
-                const uint8_t *p = A + (size_t)r * inW;
-                for (int d = -rx; d <= rx; d++) {
-                    int gx = x0 + col + d;
-                    int s = (gx >= 0 && gx < W) ? p[col + d] : ident;
-                    v = op ? (s > v ? s : v) : (s < v ? s : v);
-                }
-            }
-            B[(size_t)r * inW + col] = (uint8_t)v;
-        }
-        __syncthreads();
-        // column pass B -> A over rows [my+ry, inH-my-ry), same cols
-        const int rows2 = inH - 2 * (my + ry);
-        for (int idx = threadIdx.x; idx < rows2 * cols; idx += 256) {
-            int r = my + ry + idx / cols, col = mx + rx + idx % cols;
-            int v = ident;
-            for (int d = -ry; d <= ry; d++) {
-                int s = B[(size_t)(r + d) * inW + col];  // out-of-image rows hold ident already
-                v = op ? (s > v ? s : v) : (s < v ? s : v);
-            }
-            A[(size_t)r * inW + col] = (uint8_t)v;
-        }
-        __syncthreads();
-        mx += rx;
+        const int rx = ch.rx[o], ry = ch.ry[o];
+        c_lo += (rx + 3) >> 2;
+        const uint32_t next_ident = (o + 1 < ch.n && ch.op[o + 1] == 0) ? 0xFFFFFFFFu : 0u;
+        if (ch.op[o])
+            chain_op<true>(A, B, inWd, inH, c_lo, inWd - c_lo, my, rx, ry, X0, Y0, H, W, next_ident);
+        else
+            chain_op<false>(A, B, inWd, inH, c_lo, inWd - c_lo, my, rx, ry, X0, Y0, H, W, next_ident);
         my += ry;
     }
-    for (int idx = threadIdx.x; idx < CTH * CTW; idx += 256) {
-        int r = idx / CTW, col = idx - r * CTW;
-        int gx = x0 + RX + col, gy = y0 + RY + r;
-        if (gx < W && gy < H)
-            dimg[(size_t)gy * W + gx] = A[(size_t)(r + RY) * inW + col + RX];
+
+    for (int idx = threadIdx.x; idx < CTH * CTWD; idx += 256) {
+        const int r = idx / CTWD, cd = idx - r * CTWD;
+        const int gy = Y0 + RY + r, gx0 = X0 + 4 * (HQ + cd);
+        if (gy >= H || gx0 >= W)
+            continue;
+        const uint32_t v = A[(r + RY) * inWd + HQ + cd];
+        uint8_t *p = dimg + (size_t)gy * W + gx0;
+        if (fast) {
+            *(uint32_t *)p = v;
+        } else {
+            const int nvalid = W - gx0 < 4 ? W - gx0 : 4;
+            for (int b = 0; b < nvalid; b++)
+                p[b] = (uint8_t)(v >> (8 * b));
+        }
     }
 }
 
@@ -675,35 +807,46 @@ hipError_t morph_generic(int op, const uint8_t *src, uint8_t *dst, int n_img, in
     return hipGetLastError();
 }
 
-bool morph_rect_chain_supported(const RectChain &ch)
+namespace {
+// halo of the packed chain kernel: dwords per side, rows per side, LDS bytes
+bool chain_geometry(const RectChain &ch, int *HQ, int *RY, size_t *lds)
 {
     if (ch.n < 1 || ch.n > 8)
         return false;
-    int RX = 0, RY = 0;
+    int hq = 0, ry = 0;
     for (int i = 0; i < ch.n; i++) {
-        if (ch.rx[i] < 0 || ch.ry[i] < 0 || (ch.op[i] != 0 && ch.op[i] != 1))
+        if (ch.rx[i] < 0 || ch.ry[i] < 0 || ch.rx[i] > 4 * CMAXQ - 1 || ch.ry[i] > CMAXR ||
+            (ch.op[i] != 0 && ch.op[i] != 1))
             return false;
-        RX += ch.rx[i];
-        RY += ch.ry[i];
+        hq += (ch.rx[i] + 3) >> 2;
+        ry += ch.ry[i];
     }
-    size_t lds = 2 * ((((size_t)(CTW + 2 * RX) * (CTH + 2 * RY)) + 15) & ~(size_t)15);
-    return lds <= 64 * 1024;
+    *HQ = hq;
+    *RY = ry;
+    *lds = 2 * sizeof(uint32_t) * (size_t)(CTWD + 2 * hq) * (size_t)(CTH + 2 * ry);
+    return *lds <= 64 * 1024;
+}
+}  // namespace
+
+bool morph_rect_chain_supported(const RectChain &ch)
+{
+    int HQ, RY;
+    size_t lds;
+    return chain_geometry(ch, &HQ, &RY, &lds);
 }
 
 hipError_t morph_rect_chain(const uint8_t *src, uint8_t *dst, int n_img, int h, int w,
                             const RectChain &ch, hipStream_t s)
 {
-    if (n_img < 1 || h < 1 || w < 1 || !morph_rect_chain_supported(ch) ||
+    int HQ, RY;
+    size_t lds;
+    if (n_img < 1 || h < 1 || w < 1 || !chain_geometry(ch, &HQ, &RY, &lds) ||
         (h + CTH - 1) / CTH > 65535 || n_img > 65535)
         return hipErrorInvalidValue;
-    int RX = 0, RY = 0;
-    for (int i = 0; i < ch.n; i++) {
-        RX += ch.rx[i];
-        RY += ch.ry[i];
-    }
-    size_t lds = 2 * ((((size_t)(CTW + 2 * RX) * (CTH + 2 * RY)) + 15) & ~(size_t)15);
-    hipLaunchKernelGGL(morph_chain_kernel, grid3(w, h, n_img, CTW, CTH), dim3(256), lds, s, src,
-                       dst, h, w, ch, RX, RY);
+    // dword loads/stores need every row (and every image) to start 4-byte aligned
+    const int fast = (w % 4 == 0) && ((uintptr_t)src % 4 == 0) && ((uintptr_t)dst % 4 == 0);
+    hipLaunchKernelGGL(morph_chain_kernel, grid3(w, h, n_img, 4 * CTWD, CTH), dim3(256), lds, s,
+                       src, dst, h, w, ch, HQ, RY, fast);
     return hipGetLastError();
 }
 
