@@ -10,7 +10,8 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libgofpid_hip.so")
+# GOFPID_LIB: A/B builds of the kernels (profiles/ ablations); default is the in-tree build
+LIB_PATH = os.environ.get("GOFPID_LIB") or os.path.join(_HERE, "csrc", "libgofpid_hip.so")
 
 OK, EINVAL, EHIP, ENOMEM, ENODEV = 0, 1, 2, 3, 4
 ERODE, DILATE = 0, 1
