@@ -10,7 +10,6 @@
 #include "gof_kernels.h"
 
 #include <float.h>
-#include <stdlib.h>
 
 namespace gofk {
 
@@ -28,6 +27,8 @@ __device__ __forceinline__ int reflect101(int p, int len)
     return p < len ? p : period - p;
 }
 
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
 // ---------------------------------------------------------------------------
 // MOG2 (+ optional fused 3x3 fixed-point blur)
 // ---------------------------------------------------------------------------
@@ -35,8 +36,11 @@ __device__ __forceinline__ int reflect101(int p, int len)
 // cv.createBackgroundSubtractorMOG2().apply at pipeline.py:232/470; the
 // arithmetic is cv2's, restated in oracle/gof_oracle.c.
 //
-// One pixel per lane: every model-plane access of a wave is one 256-B
-// contiguous segment (see the strip kernel below).
+// Tile = 64 px x 4 rows, one wave per row, one pixel per lane: every model
+// plane access of a wave is one 256-B contiguous segment.
+
+constexpr int TW = 64;
+constexpr int TH = 4;
 
 template <int C>
 struct PixelModel {
@@ -223,229 +227,143 @@ __device__ __forceinline__ int reflect1(int p, int len)
     return p;
 }
 
-// Strip kernel.  Every WAVE owns a 64-px-wide strip of R consecutive rows and
-// walks down it; waves never synchronise with each other (no __syncthreads).
-// While row y is being updated, the loads of row y+1 are already in flight:
-//   - mode count + mode 0 of the model (what almost every pixel needs),
-//   - the raw bytes of frame row y+2 (for the fused 3x3 blur),
-// so each wave always has a load outstanding and the HBM latency of one row
-// hides behind the arithmetic of the previous one.  The horizontal blur pass
-// of a frame row is computed once (through a wave-private LDS row buffer: one
-// coalesced dword load per lane, then each lane picks its 3 neighbours with
-// v_alignbyte) and reused by the three output rows that need it.
-constexpr int SW = 64;   // strip width: one wave, one pixel per lane
-
-template <int C>
-struct ModePrefetch {
-    int nm;
-    float w, var, mu[C];
-};
-
 template <int C, bool BLUR3>
 __global__ __launch_bounds__(256) void mog2_kernel(const uint8_t *__restrict__ frame,
                                                    uint8_t *__restrict__ mask,
                                                    float *__restrict__ planes,
                                                    uint8_t *__restrict__ modes, size_t np, int H,
-                                                   int W, int R, Mog2Consts k, uint32_t kx012,
+                                                   int W, Mog2Consts k, uint32_t kx012,
                                                    uint32_t ky012)
 {
     constexpr int F = 2 + C;  // floats per mode
     const int lane = threadIdx.x & 63;
-    // wave-uniform values are forced into SGPRs: strip origin, row bases, plane bases
+    // wave-uniform values are forced into SGPRs: row index, row bases, plane bases
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int x0 = (blockIdx.x * 4 + wave) * SW;
-    const int y0 = blockIdx.y * R;
-    if (x0 >= W || y0 >= H)
-        return;  // whole wave leaves; nobody waits for it
-    const int rows = (H - y0) < R ? (H - y0) : R;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
     const int img = blockIdx.z;
+    const int x = x0 + lane, y = y0 + wave;
     const size_t N = (size_t)H * W;
     const uint8_t *fimg = frame + (size_t)img * N * C;
-    const int x = x0 + lane;
-    const bool valid = x < W;
-    const unsigned xl = valid ? (unsigned)x : (unsigned)(W - 1);   // in-bounds for idle lanes
 
-    // dwords per staged frame row: (SW+2) px, misalignment slack, one of read-ahead
-    constexpr int ROWD = ((SW + 2) * C + 3 + 3) / 4 + 1;
-    constexpr int NRAW = (ROWD + 63) / 64;
-    __shared__ uint32_t rowbuf[BLUR3 ? 4 * ROWD : 1];
-    uint32_t *myrow = rowbuf + (BLUR3 ? wave * ROWD : 0);
+    // ---- stage the (TH+2) x (TW+2) px input tile: raw bytes, aligned dword
+    //      loads, each wave stages rows {wave, wave+4}; borders are resolved
+    //      when the tile is read ----
+    // dwords per staged row: misalignment slack + one dword of read-ahead for px()
+    constexpr int ROWD = ((TW + 2) * C + 3 + 3) / 4 + 1;
+    __shared__ uint32_t tile[BLUR3 ? (TH + 2) * ROWD : 1];
     const int sx0 = x0 > 0 ? x0 - 1 : 0;
-    const int sx1 = (x0 + SW + 1) < W ? (x0 + SW + 1) : W;
-    const int nb = (sx1 - sx0) * C;
-    const int kx0 = (int)(kx012 & 1023), kx1 = (int)((kx012 >> 10) & 1023), kx2 = (int)(kx012 >> 20);
-    const int ky0 = (int)(ky012 & 1023), ky1 = (int)((ky012 >> 10) & 1023), ky2 = (int)(ky012 >> 20);
-    const int pl = (reflect1((int)xl - 1, W) - sx0) * C, pc = ((int)xl - sx0) * C,
-              pr = (reflect1((int)xl + 1, W) - sx0) * C;
-
-    struct Raw {
-        uint32_t d[NRAW];
-        int mis;
-    };
-    // issue the coalesced dword loads of frame row gy (bytes [sx0*C, sx1*C))
-    auto frame_issue = [&](int gy) -> Raw {
-        Raw r;
-        const uint8_t *a = fimg + ((size_t)gy * W + sx0) * C;
-        r.mis = (int)((uintptr_t)a & 3);
-        const int ndw = (r.mis + nb + 3) >> 2;
-        const uint32_t *a4 = (const uint32_t *)(a - r.mis);
-#pragma unroll
-        for (int i = 0; i < NRAW; i++) {
-            const int d = lane + 64 * i;
-            r.d[i] = d < ndw ? a4[d] : 0u;
-        }
-        return r;
-    };
-    // horizontal 3-tap pass of that row for this lane's pixel: exact u16 sums
-    auto frame_finish = [&](const Raw &r, uint32_t (&h)[C]) {
-#pragma unroll
-        for (int i = 0; i < NRAW; i++)
-            if (lane + 64 * i < ROWD)
-                myrow[lane + 64 * i] = r.d[i];
-        __builtin_amdgcn_wave_barrier();
-        auto px = [&](int o) -> uint32_t {
-            o += r.mis;
-            const uint32_t lo = myrow[o >> 2], hi = myrow[(o >> 2) + 1];
-            return __builtin_amdgcn_alignbyte(hi, lo, (unsigned)(o & 3));
-        };
-        const uint32_t L = px(pl), Cn = px(pc), Rr = px(pr);
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int c = 0; c < C; c++)
-            h[c] = kx0 * ((L >> (8 * c)) & 255u) + kx1 * ((Cn >> (8 * c)) & 255u) +
-                   kx2 * ((Rr >> (8 * c)) & 255u);
-    };
-    // raw pixel of row gy (no blur)
-    auto pixel_issue = [&](int gy, uint32_t (&h)[C]) {
-        const uint8_t *fp = fimg + ((size_t)gy * W + xl) * C;
-#pragma unroll
-        for (int c = 0; c < C; c++)
-            h[c] = fp[c];
-    };
-    // mode count + mode 0 of row gy
-    auto model_issue = [&](int gy) -> ModePrefetch<C> {
-        ModePrefetch<C> p;
-        const size_t rowoff = (size_t)img * N + (size_t)gy * W;   // wave-uniform
-        const float *prow = planes + rowoff;
-        p.nm = modes[rowoff + xl];
-        p.w = prow[xl];
-        p.var = (prow + np)[xl];
-#pragma unroll
-        for (int c = 0; c < C; c++)
-            p.mu[c] = (prow + (size_t)(2 + c) * np)[xl];
-        return p;
-    };
-
-    // ---- prologue: rows y0-1, y0, y0+1 of the frame; model row y0 ----
-    uint32_t hA[C], hB[C], hC[C];   // horizontal sums of rows y-1, y, y+1 (or the raw pixel in hB)
-    Raw rawN;
-    ModePrefetch<C> pf0 = model_issue(y0), pf1 = pf0;
     if (BLUR3) {
-        Raw ra = frame_issue(reflect1(y0 - 1, H)), rb = frame_issue(y0),
-            rc = frame_issue(reflect1(y0 + 1, H));
-        frame_finish(ra, hA);
-        frame_finish(rb, hB);
-        frame_finish(rc, hC);
-        rawN = rc;
-    } else {
-        pixel_issue(y0, hB);
+        const int sx1 = (x0 + TW + 1) < W ? (x0 + TW + 1) : W;
+        const int nb = (sx1 - sx0) * C;
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++) {
+            const int r = wave + 4 * rr;
+            if (r < TH + 2) {
+                const int gy = clampi(reflect1(y0 - 1 + r, H), 0, H - 1);
+                const uint8_t *a = fimg + ((size_t)gy * W + sx0) * C;
+                const int mis = (int)((uintptr_t)a & 3);
+                const int ndw = (mis + nb + 3) >> 2;
+                for (int d = lane; d < ndw; d += 64)
+                    tile[r * ROWD + d] = ((const uint32_t *)(a - mis))[d];
+            }
+        }
     }
 
-    // One row.  `cur` holds this row's prefetched mode 0, `nxt` receives the next
-    // row's.  The two are distinct register sets (the loop below alternates
-    // them) so that nothing has to be copied out of a load still in flight.
-    // Issue order matters because vmcnt retires in order: first this row's
-    // extra modes (needed soonest), then the prefetch (needed one row later).
-    auto row_step = [&](int i, const ModePrefetch<C> &cur, ModePrefetch<C> &nxt) {
-        const int y = y0 + i;
-        const size_t rowoff = (size_t)img * N + (size_t)y * W;
-        float *const prow = planes + rowoff;
-        PixelModel<C> M;
-        int nmodes = cur.nm;
-        M.w[0] = cur.w;
-        M.var[0] = cur.var;
+    // ---- model: plane p of this wave's row starts at a wave-uniform address,
+    //      the lane only adds x; mode count + mode 0 are loaded speculatively ----
+    const bool rowok = y < H;
+    const int yy = rowok ? y : 0;
+    const bool valid = rowok && x < W;
+    const unsigned xl = valid ? (unsigned)x : 0u;           // lane offset within the row
+    const size_t rowoff = (size_t)img * N + (size_t)yy * W; // wave-uniform
+    float *const prow = planes + rowoff;
+    PixelModel<C> M;
+    int nmodes = modes[rowoff + xl];
+    M.w[0] = prow[xl];
+    M.var[0] = (prow + np)[xl];
+#pragma unroll
+    for (int c = 0; c < C; c++)
+        M.mu[0][c] = (prow + (size_t)(2 + c) * np)[xl];
+
+    float xin[C];
+    if (BLUR3) {
+        __syncthreads();
+        const int kx0 = (int)(kx012 & 1023), kx1 = (int)((kx012 >> 10) & 1023), kx2 = (int)(kx012 >> 20);
+        const int ky[3] = {(int)(ky012 & 1023), (int)((ky012 >> 10) & 1023), (int)(ky012 >> 20)};
+        // byte offsets (within a staged row) of the left / centre / right pixel
+        const int xc = valid ? x : sx0;
+        const int pl = (reflect1(xc - 1, W) - sx0) * C, pc = (xc - sx0) * C,
+                  pr = (reflect1(xc + 1, W) - sx0) * C;
+        uint32_t acc[C];
 #pragma unroll
         for (int c = 0; c < C; c++)
-            M.mu[0][c] = cur.mu[c];
+            acc[c] = 32768u;
 #pragma unroll
-        for (int m = 1; m < kMaxModes; m++) {
-            if (valid && m < nmodes) {
-                const float *pm = prow + (size_t)m * F * np;
-                M.w[m] = pm[xl];
-                M.var[m] = (pm + np)[xl];
-#pragma unroll
-                for (int c = 0; c < C; c++)
-                    M.mu[m][c] = (pm + (size_t)(2 + c) * np)[xl];
-            } else {
-                M.w[m] = 0.f;
-                M.var[m] = 0.f;
-#pragma unroll
-                for (int c = 0; c < C; c++)
-                    M.mu[m][c] = 0.f;
-            }
-        }
-
-        // The prefetch is issued unconditionally (the row index is clamped at the
-        // image end): a fixed number of loads after this row's extra-mode loads is
-        // what lets the compiler wait for those with a counted vmcnt instead of
-        // draining the prefetch as well.
-        uint32_t hN[C];
-        {
-            const int yn = (y + 1 < H) ? y + 1 : H - 1;
-            if (BLUR3)
-                rawN = frame_issue(reflect1(y + 2, H));
-            else
-                pixel_issue(yn, hN);
-            nxt = model_issue(yn);
-        }
-
-        if (valid) {
-            float xin[C];
-#pragma unroll
-            for (int c = 0; c < C; c++)
-                xin[c] = BLUR3 ? (float)((32768u + ky0 * hA[c] + ky1 * hB[c] + ky2 * hC[c]) >> 16)
-                               : (float)hB[c];
-#if defined(GOF_ABLATE_NOCOMPUTE)   // profiles/: memory path only, results are wrong
-            M.w[0] += xin[0] + xin[C - 1];
-            const uint8_t out = (uint8_t)nmodes;
-            (void)k;
-#else
-            const uint8_t out = mog2_update<C>(M, nmodes, xin, k);
-#endif
-#pragma unroll
-            for (int m = 0; m < kMaxModes; m++) {
-                if (m < nmodes) {
-                    float *pm = prow + (size_t)m * F * np;
-                    pm[xl] = M.w[m];
-                    (pm + np)[xl] = M.var[m];
-#pragma unroll
-                    for (int c = 0; c < C; c++)
-                        (pm + (size_t)(2 + c) * np)[xl] = M.mu[m][c];
-                }
-            }
-            modes[rowoff + xl] = (uint8_t)nmodes;
-            mask[rowoff + xl] = out;
-        }
-
-        if (BLUR3) {
+        for (int j = 0; j < 3; j++) {
+            const int r = wave + j;
+            const int gy = clampi(reflect1(y0 - 1 + r, H), 0, H - 1);
+            const int mis = (int)((uintptr_t)(fimg + ((size_t)gy * W + sx0) * C) & 3);
+            const uint32_t *row = tile + r * ROWD;
+            // C consecutive bytes starting at byte offset o of the staged row
+            auto px = [&](int o) -> uint32_t {
+                o += mis;
+                const uint32_t lo = row[o >> 2], hi = row[(o >> 2) + 1];
+                return __builtin_amdgcn_alignbyte(hi, lo, (unsigned)(o & 3));
+            };
+            const uint32_t L = px(pl), Cn = px(pc), R = px(pr);
 #pragma unroll
             for (int c = 0; c < C; c++) {
-                hA[c] = hB[c];
-                hB[c] = hC[c];
+                const uint32_t hsum = kx0 * ((L >> (8 * c)) & 255u) + kx1 * ((Cn >> (8 * c)) & 255u) +
+                                      kx2 * ((R >> (8 * c)) & 255u);
+                acc[c] += ky[j] * hsum;
             }
-            frame_finish(rawN, hC);
-        } else {
+        }
+#pragma unroll
+        for (int c = 0; c < C; c++)
+            xin[c] = (float)(acc[c] >> 16);
+    } else {
+        const uint8_t *fp = fimg + ((size_t)yy * W + xl) * C;
+#pragma unroll
+        for (int c = 0; c < C; c++)
+            xin[c] = (float)fp[c];
+    }
+    if (!valid)
+        return;
+
+    // ---- remaining modes, predicated on the pixel's own mode count ----
+#pragma unroll
+    for (int m = 1; m < kMaxModes; m++) {
+        if (m < nmodes) {
+            const float *pm = prow + (size_t)m * F * np;
+            M.w[m] = pm[xl];
+            M.var[m] = (pm + np)[xl];
 #pragma unroll
             for (int c = 0; c < C; c++)
-                hB[c] = hN[c];
+                M.mu[m][c] = (pm + (size_t)(2 + c) * np)[xl];
+        } else {
+            M.w[m] = 0.f;
+            M.var[m] = 0.f;
+#pragma unroll
+            for (int c = 0; c < C; c++)
+                M.mu[m][c] = 0.f;
         }
-    };
-
-    for (int i = 0; i < rows; i += 2) {
-        row_step(i, pf0, pf1);
-        if (i + 1 < rows)
-            row_step(i + 1, pf1, pf0);
     }
+
+    uint8_t out = mog2_update<C>(M, nmodes, xin, k);
+
+#pragma unroll
+    for (int m = 0; m < kMaxModes; m++) {
+        if (m < nmodes) {
+            float *pm = prow + (size_t)m * F * np;
+            pm[xl] = M.w[m];
+            (pm + np)[xl] = M.var[m];
+#pragma unroll
+            for (int c = 0; c < C; c++)
+                (pm + (size_t)(2 + c) * np)[xl] = M.mu[m][c];
+        }
+    }
+    modes[rowoff + xl] = (uint8_t)nmodes;
+    mask[rowoff + xl] = out;
 }
 
 // ---------------------------------------------------------------------------
@@ -825,18 +743,8 @@ hipError_t mog2_apply(const uint8_t *frame, uint8_t *mask, const Mog2State &st, 
                       int w, int c, const Mog2Consts &k, bool fused_blur3, const Taps &t,
                       hipStream_t s)
 {
-    if (n_img < 1 || h < 1 || w < 1 || n_img > 65535 || st.np < (size_t)n_img * h * w ||
-        k.nmix < 1 || k.nmix > kMaxModes)
-        return hipErrorInvalidValue;
-    // rows per strip: enough strips to fill the chip a few times over (256 CUs x
-    // 4 SIMDs x ~5 resident waves), long enough to amortise the 2-row prologue
-    const long strips_x = (w + SW - 1) / SW;
-    long R = (strips_x * h * n_img) / (4L * 256 * 4 * 5);
-    R = R < 4 ? 4 : (R > 16 ? 16 : R);
-    if (const char *e = getenv("GOF_STRIP_ROWS"))   // tuning knob (profiles/ sweeps)
-        if (atoi(e) > 0)
-            R = atoi(e);
-    if ((h + R - 1) / R > 65535)
+    if (n_img < 1 || h < 1 || w < 1 || (h + TH - 1) / TH > 65535 || n_img > 65535 ||
+        st.np < (size_t)n_img * h * w || k.nmix < 1 || k.nmix > kMaxModes)
         return hipErrorInvalidValue;
     if (fused_blur3 && (t.nkx != 3 || t.nky != 3))
         return hipErrorInvalidValue;
@@ -845,10 +753,10 @@ hipError_t mog2_apply(const uint8_t *frame, uint8_t *mask, const Mog2State &st, 
         kx = t.kx[0] | (t.kx[1] << 10) | (t.kx[2] << 20);
         ky = t.ky[0] | (t.ky[1] << 10) | (t.ky[2] << 20);
     }
-    dim3 g = grid3(w, h, n_img, 4 * SW, (int)R);
+    dim3 g = grid3(w, h, n_img, TW, TH);
 #define GOF_LAUNCH_MOG2(CC, BB)                                                              \
     hipLaunchKernelGGL((mog2_kernel<CC, BB>), g, dim3(256), 0, s, frame, mask, st.planes,    \
-                       st.modes, st.np, h, w, (int)R, k, kx, ky)
+                       st.modes, st.np, h, w, k, kx, ky)
     if (fused_blur3) {
         switch (c) {
         case 1: GOF_LAUNCH_MOG2(1, true); break;
