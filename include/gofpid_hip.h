@@ -105,6 +105,13 @@ void gof_destroy(gof_ctx *ctx);
 int gof_synchronize(gof_ctx *ctx);
 void *gof_stream(gof_ctx *ctx);        /* the context's hipStream_t */
 
+/* ---- step 0 (optional): colour conversion (replaces cv.cvtColor(X, code) for
+ *      COLOR_BGR2GRAY / COLOR_RGB2GRAY, pipeline.py:458-459) ---------------- */
+int gof_cvt_gray_host(gof_ctx *ctx, const uint8_t *src, uint8_t *dst, int h, int w, int c,
+                      int rgb_order);
+int gof_cvt_gray_dev(gof_ctx *ctx, const void *d_src, void *d_dst, int n_images, int h, int w,
+                     int c, int rgb_order, void *stream);
+
 /* ---- step 1: blur  (replaces cv.GaussianBlur, pipeline.py:463-467) ------ */
 /* cv.GaussianBlur(src, (kw, kh), sigma_x, sigmaY = sigma_y) on uint8 with
  * BORDER_REFLECT_101.  NB the reference passes blur['borderType'] as the 3rd
@@ -166,6 +173,16 @@ int gof_pipeline_mean_modes(gof_pipeline *p, double *mean_modes);
  *       and 2*c B/px for a blur that is not fused). */
 int gof_pipeline_algorithmic_bytes(gof_pipeline *p, double mean_modes, double *total_bytes,
                                    double *detector_bytes);
+
+/* ---- step 4 helper, host only (NOT part of the GPU hot path) -------------
+ * cv.findContours(mask, RETR_EXTERNAL, CHAIN_APPROX_NONE) as the reference's
+ * helpers.find_contours calls it (helpers.py:139-143): Suzuki-Abe border
+ * following on the host.  Returns library-allocated arrays (release each with
+ * gof_free): points_xy = (x, y) int32 pairs of all contours back to back,
+ * offsets[k]..offsets[k+1] = the point range of contour k. */
+int gof_find_external_contours(const uint8_t *mask, int h, int w, int32_t **points_xy,
+                               int32_t **offsets, int *n_contours);
+void gof_free(void *p);
 
 /* Per-kernel timing with HIP events on the launch stream (what bench.py's
  * roofline block is computed from).  enable != 0: every following apply

@@ -94,6 +94,8 @@ def lib():
         L.gofo_gaussian_blur.argtypes = [_u8p, _u8p, C.c_int, C.c_int, C.c_int,
                                          C.c_int, C.c_int, C.c_double, C.c_double]
         L.gofo_gaussian_blur.restype = C.c_int
+        L.gofo_cvt_gray.argtypes = [_u8p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.gofo_cvt_gray.restype = None
         L.gofo_mog2_default_params.argtypes = [C.POINTER(Mog2Params)]
         L.gofo_mog2_create.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(Mog2Params)]
         L.gofo_mog2_create.restype = C.c_void_p
@@ -146,6 +148,14 @@ def gaussian_blur(x, ksize=(3, 3), sigma_x=4.0, sigma_y=0.0):
     if lib().gofo_gaussian_blur(_p8(x), _p8(out), h, w, c, int(ksize[0]), int(ksize[1]),
                                 float(sigma_x), float(sigma_y)):
         raise ValueError("bad Gaussian ksize %r" % (ksize,))
+    return out
+
+
+def cvt_gray(x, rgb_order=False):
+    """cv.cvtColor(x, COLOR_BGR2GRAY) (COLOR_RGB2GRAY when rgb_order)."""
+    x, h, w, c = _as_hwc(x)
+    out = np.empty((h, w), dtype=np.uint8)
+    lib().gofo_cvt_gray(_p8(x), _p8(out), h, w, c, int(bool(rgb_order)))
     return out
 
 

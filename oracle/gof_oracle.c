@@ -70,6 +70,21 @@ static int reflect101(int p, int len)
 int gofo_reflect101(int p, int len) { return reflect101(p, len); }
 
 /* ------------------------------------------------------------------------- */
+/* cv.cvtColor(X, COLOR_BGR2GRAY | COLOR_RGB2GRAY)  [REF pipeline.py:458-459]  */
+/* OpenCV 3.4 (the line the reference pins) [OPENCV-RECALL]: yuv_shift = 14,   */
+/* R2Y = 4899, G2Y = 9617, B2Y = 1868, CV_DESCALE rounding.                    */
+/* ------------------------------------------------------------------------- */
+void gofo_cvt_gray(const uint8_t *src, uint8_t *dst, int h, int w, int c, int rgb_order)
+{
+    size_t n = (size_t)h * w;
+    int c0 = rgb_order ? 4899 : 1868, c2 = rgb_order ? 1868 : 4899;
+    for (size_t i = 0; i < n; i++) {
+        const uint8_t *p = src + i * c;
+        dst[i] = (uint8_t)((p[0] * c0 + p[1] * 9617 + p[2] * c2 + (1 << 13)) >> 14);
+    }
+}
+
+/* ------------------------------------------------------------------------- */
 /* Gaussian blur, 8-bit fixed point   [OPENCV-RECALL]          */
 /* ------------------------------------------------------------------------- */
 

@@ -59,6 +59,9 @@ SIGNATURES = {
     "gof_destroy": (None, [C.c_void_p]),
     "gof_synchronize": (C.c_int, [C.c_void_p]),
     "gof_stream": (C.c_void_p, [C.c_void_p]),
+    "gof_cvt_gray_host": (C.c_int, [C.c_void_p, _u8p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "gof_cvt_gray_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                   C.c_int, C.c_int, C.c_void_p]),
     "gof_gaussian_blur_host": (C.c_int, [C.c_void_p, _u8p, _u8p, C.c_int, C.c_int, C.c_int,
                                          C.c_int, C.c_int, C.c_double, C.c_double]),
     "gof_gaussian_blur_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
@@ -95,6 +98,11 @@ SIGNATURES = {
     "gof_pipeline_mean_modes": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "gof_pipeline_algorithmic_bytes": (C.c_int, [C.c_void_p, C.c_double, C.POINTER(C.c_double),
                                                  C.POINTER(C.c_double)]),
+    "gof_find_external_contours": (C.c_int, [_u8p, C.c_int, C.c_int,
+                                             C.POINTER(C.POINTER(C.c_int32)),
+                                             C.POINTER(C.POINTER(C.c_int32)),
+                                             C.POINTER(C.c_int)]),
+    "gof_free": (None, [C.c_void_p]),
     "gof_pipeline_profile_enable": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "gof_pipeline_profile_query": (C.c_int, [C.c_void_p, C.POINTER(C.c_double),
                                              C.POINTER(C.c_double), C.POINTER(C.c_int)]),

@@ -369,6 +369,42 @@ int gof_gaussian_blur_host(gof_ctx *ctx, const uint8_t *src, uint8_t *dst, int h
     return GOF_OK;
 }
 
+/* ---- colour conversion --------------------------------------------------- */
+
+int gof_cvt_gray_dev(gof_ctx *ctx, const void *d_src, void *d_dst, int n_images, int h, int w,
+                     int c, int rgb_order, void *stream)
+{
+    if (!ctx || !d_src || !d_dst)
+        return fail(GOF_EINVAL, "NULL argument");
+    if (n_images < 1 || h < 1 || w < 1 || (c != 3 && c != 4))
+        return fail(GOF_EINVAL, "cvtColor to gray needs 3 or 4 channels, got images=%d h=%d w=%d c=%d",
+                    n_images, h, w, c);
+    GOF_HIP(hipSetDevice(ctx->device));
+    GOF_HIP(gofk::cvt_gray((const uint8_t *)d_src, (uint8_t *)d_dst, n_images, h, w, c,
+                           rgb_order != 0, pick(ctx, stream)));
+    return GOF_OK;
+}
+
+int gof_cvt_gray_host(gof_ctx *ctx, const uint8_t *src, uint8_t *dst, int h, int w, int c,
+                      int rgb_order)
+{
+    if (!ctx || !src || !dst)
+        return fail(GOF_EINVAL, "NULL argument");
+    if (h < 1 || w < 1 || (c != 3 && c != 4))
+        return fail(GOF_EINVAL, "cvtColor to gray needs 3 or 4 channels");
+    size_t npx = (size_t)h * w;
+    int rc;
+    GOF_HIP(hipSetDevice(ctx->device));
+    if ((rc = ctx->in.reserve(npx * c)) || (rc = ctx->out.reserve(npx)))
+        return rc;
+    GOF_HIP(hipMemcpyAsync(ctx->in.p, src, npx * c, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = gof_cvt_gray_dev(ctx, ctx->in.p, ctx->out.p, 1, h, w, c, rgb_order, nullptr)))
+        return rc;
+    GOF_HIP(hipMemcpyAsync(dst, ctx->out.p, npx, hipMemcpyDeviceToHost, ctx->stream));
+    GOF_HIP(hipStreamSynchronize(ctx->stream));
+    return GOF_OK;
+}
+
 /* ---- MOG2 ---------------------------------------------------------------- */
 
 void gof_mog2_default_params(gof_mog2_params *p)

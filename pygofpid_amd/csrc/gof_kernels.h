@@ -68,6 +68,10 @@ hipError_t morph_rect_chain(const uint8_t *src, uint8_t *dst, int n_img, int h, 
                             const RectChain &ch, hipStream_t s);
 bool morph_rect_chain_supported(const RectChain &ch);
 
+// (h,w,c in {3,4}) -> (h,w) luma, BGR order unless rgb
+hipError_t cvt_gray(const uint8_t *src, uint8_t *dst, int n_img, int h, int w, int c, bool rgb,
+                    hipStream_t s);
+
 // sum of modes[] (for m-bar); out is a device uint64 accumulator, zeroed by caller.
 hipError_t sum_modes(const uint8_t *modes, size_t n, unsigned long long *out, hipStream_t s);
 

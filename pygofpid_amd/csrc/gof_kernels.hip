@@ -696,6 +696,22 @@ __global__ __launch_bounds__(256) void morph_chain_kernel(const uint8_t *__restr
     }
 }
 
+// ---------------------------------------------------------------------------
+// step 0 (optional): cv.cvtColor(X, COLOR_BGR2GRAY | COLOR_RGB2GRAY), pipeline.py:458-459
+// 8-bit fixed point of the OpenCV 3.4 line the reference pins [OPENCV-RECALL]:
+//   Y = (B*1868 + G*9617 + R*4899 + 2^13) >> 14
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gray_kernel(const uint8_t *__restrict__ src,
+                                                   uint8_t *__restrict__ dst, size_t npix, int c,
+                                                   int c0, int c1, int c2)
+{
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npix)
+        return;
+    const uint8_t *p = src + i * c;
+    dst[i] = (uint8_t)((p[0] * c0 + p[1] * c1 + p[2] * c2 + (1 << 13)) >> 14);
+}
+
 __global__ __launch_bounds__(256) void sum_modes_kernel(const uint8_t *__restrict__ modes, size_t n,
                                                         unsigned long long *out)
 {
@@ -847,6 +863,21 @@ hipError_t morph_rect_chain(const uint8_t *src, uint8_t *dst, int n_img, int h, 
     const int fast = (w % 4 == 0) && ((uintptr_t)src % 4 == 0) && ((uintptr_t)dst % 4 == 0);
     hipLaunchKernelGGL(morph_chain_kernel, grid3(w, h, n_img, 4 * CTWD, CTH), dim3(256), lds, s,
                        src, dst, h, w, ch, HQ, RY, fast);
+    return hipGetLastError();
+}
+
+hipError_t cvt_gray(const uint8_t *src, uint8_t *dst, int n_img, int h, int w, int c, bool rgb,
+                    hipStream_t s)
+{
+    if (n_img < 1 || h < 1 || w < 1 || (c != 3 && c != 4))
+        return hipErrorInvalidValue;
+    size_t npix = (size_t)n_img * h * w;
+    size_t blocks = (npix + 255) / 256;
+    if (blocks > 0x7fffffffu)
+        return hipErrorInvalidValue;
+    const int B2Y = 1868, G2Y = 9617, R2Y = 4899;
+    hipLaunchKernelGGL(gray_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, dst, npix, c,
+                       rgb ? R2Y : B2Y, G2Y, rgb ? B2Y : R2Y);
     return hipGetLastError();
 }
 

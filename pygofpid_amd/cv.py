@@ -62,6 +62,21 @@ def getStructuringElement(shape, ksize, anchor=(-1, -1)):
     raise ValueError("unknown structuring element shape %r" % (shape,))
 
 
+def cvtColor(src, code):
+    """cv.cvtColor for the two codes the reference's tests use
+    (COLOR_BGR2GRAY, COLOR_RGB2GRAY; pipeline.py:458-459): 8-bit fixed-point luma
+    of the OpenCV 3.4 line, Y = (1868 B + 9617 G + 4899 R + 2^13) >> 14."""
+    if code not in (COLOR_BGR2GRAY, COLOR_RGB2GRAY):
+        raise ValueError("only COLOR_BGR2GRAY / COLOR_RGB2GRAY are built")
+    x = _lib.as_u8(src, "src")
+    x, h, w, c = _lib.hwc(x)
+    out = np.empty((h, w), np.uint8)
+    ctx = _lib.default_context()
+    _lib.check(_lib.load().gof_cvt_gray_host(ctx.handle, _lib.p8(x), _lib.p8(out), h, w, c,
+                                             int(code == COLOR_RGB2GRAY)))
+    return out
+
+
 def GaussianBlur(src, ksize, sigmaX, dst=None, sigmaY=0, borderType=BORDER_DEFAULT):
     """cv.GaussianBlur on uint8: 8.8 fixed-point separable filter, REFLECT_101.
 

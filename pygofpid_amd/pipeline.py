@@ -1,0 +1,394 @@
+"""GOFPID: good old fashioned perimeter intrusion detection, MI355X foreground path.
+
+Drop-in for `pygofpid.pipeline.GOFPID` (reference pygofpid/pipeline.py:22-853):
+same constructor arguments and defaults, `initialize()`, `detect(X) -> bool`,
+`display(X, display)`, and the attributes `foreground_mask_`, `blobs_`,
+`tracked_blobs_`, `input_shape_`.
+
+What runs where
+  steps 1-3 (blur, background subtraction, morphology; reference :461-476)
+      on the GPU.  When the configured callables are this package's own
+      (`cv.GaussianBlur`, 'MOG2' | 'FD', `cv.erode` / `cv.dilate`) the three
+      steps are ONE `ForegroundPipeline` step: one upload, fused kernels, one
+      download of the mask.  Any other callables are called exactly as the
+      reference calls them (`fun(X, ksize, borderType)`, `.apply(X)`,
+      `fun(mask, kernel)`).
+  steps 4-7 (blobs, tracking, post-filter, alarm; reference :478-491) on the
+      host, on `pygofpid_amd.hostcv` (no cv2 needed).
+
+Deliberate deviations, all off the hot path:
+  * dict / list defaults are copied per instance (the reference shares and
+    mutates its mutable defaults);
+  * 'KNN' and 'ViBe' detectors and the interactive `display_config` windows
+    are not built (NotImplementedError), see SURVEY.md section 2 rows 7, 8, 11.
+"""
+import numpy as np
+
+from . import cv, hostcv
+from .foreground import ForegroundPipeline
+from .helpers import (SimpleLinearRegression, find_contours, get_bottom, get_center,
+                      unnormalize_coords)
+from .segmentation import FrameDifferencing
+
+_DEFAULT_BLUR = {'fun': cv.GaussianBlur, 'ksize': (3, 3), 'borderType': cv.BORDER_DEFAULT}
+_DEFAULT_TRACKING = {'factor': 1.5, 'absence_max': 10}
+_DEFAULT_POST_FILTER = {'perimeter': None, 'anchor': 'bottom', 'perspective': None,
+                        'perspective_coeff': 0.5, 'presence_min': 3, 'distance_min': 0.25}
+_DEFAULT_ALARM = {'keep_alarm': True, 'duration_min': 10}
+_UNSET = object()
+
+
+def _default_morph():
+    k = cv.getStructuringElement(cv.MORPH_RECT, (5, 5))
+    return [{'fun': cv.erode, 'kernel': k}, {'fun': cv.dilate, 'kernel': k.copy()}]
+
+
+def _require(mapping, key, name):
+    if key not in mapping.keys():
+        raise KeyError('Parameter %s has no key "%s".' % (name, key))
+
+
+class GOFPID():
+    """See the module docstring; parameters as in the reference (pipeline.py:37-127)."""
+
+    def __init__(self, convert=None, blur=_UNSET, frg_detect='MOG2', mat_morph=_UNSET,
+                 tracking=_UNSET, post_filter=_UNSET, alarm_def=_UNSET, verbose=False):
+        self.convert = convert
+        self.blur = dict(_DEFAULT_BLUR) if blur is _UNSET else blur
+        self.frg_detect = frg_detect
+        self.mat_morph = _default_morph() if mat_morph is _UNSET else mat_morph
+        self.tracking = dict(_DEFAULT_TRACKING) if tracking is _UNSET else tracking
+        self.post_filter = dict(_DEFAULT_POST_FILTER) if post_filter is _UNSET else post_filter
+        self.alarm_def = dict(_DEFAULT_ALARM) if alarm_def is _UNSET else alarm_def
+        self.verbose = verbose
+
+    # ------------------------------------------------------------------ init
+    def initialize(self):
+        """Check parameters and set the pipeline up (reference pipeline.py:214-283).
+        Nothing is allocated on the GPU here: the frame size is only known at the
+        first detect()."""
+        if self.blur:
+            _require(self.blur, 'fun', 'blur')
+            self.blur.setdefault('ksize', (3, 3))
+            self.blur.setdefault('borderType', cv.BORDER_DEFAULT)
+
+        if self.frg_detect == 'MOG2':
+            self._frg_detect_mth = cv.createBackgroundSubtractorMOG2()
+        elif self.frg_detect == 'FD':
+            self._frg_detect_mth = FrameDifferencing()
+        elif self.frg_detect in ('KNN', 'ViBe'):
+            raise NotImplementedError(
+                "frg_detect=%r is outside the MI355X foreground path (MOG2 and FD are built)"
+                % self.frg_detect)
+        else:
+            raise ValueError('Unknown method for foreground detection')
+
+        if self.mat_morph:
+            for d in self.mat_morph:
+                _require(d, 'fun', 'mat_morph')
+                if 'kernel' not in d.keys():
+                    d['kernel'] = cv.getStructuringElement(cv.MORPH_RECT, (5, 5))
+
+        _require(self.tracking, 'factor', 'tracking')
+        _require(self.tracking, 'absence_max', 'tracking')
+
+        _require(self.post_filter, 'anchor', 'post_filter')
+        if self.post_filter['anchor'] not in ['bottom', 'center']:
+            raise ValueError('Parameter anchor must be "bottom" or "center".')
+        for key in ('perspective_coeff', 'presence_min', 'distance_min'):
+            _require(self.post_filter, key, 'post_filter')
+        self._check_perimeter()
+        self._check_perspective()
+
+        _require(self.alarm_def, 'keep_alarm', 'alarm_def')
+        _require(self.alarm_def, 'duration_min', 'alarm_def')
+
+        self.tracked_blobs_ = []
+        self.input_shape_ = None
+        self._alarm_system = {'already_in_alarm': False, 'duration': 0}
+        self._fused = None          # ForegroundPipeline, built at the first frame
+        self._fused_checked = False
+        return self
+
+    def _check_polygon_param(self, key, default, check):
+        _require(self.post_filter, key, 'post_filter')
+        value = self.post_filter[key]
+        if value is None:
+            self.post_filter[key] = np.array(default)
+        elif isinstance(value, np.ndarray):
+            check(value)
+        else:
+            raise ValueError('Unknown type for parameter "%s".' % key)
+        if self.post_filter.get('display_config'):
+            raise NotImplementedError(
+                'display_config opens interactive cv2 windows (reference pipeline.py:308-407); '
+                'not available in this headless build')
+
+    def _check_perimeter(self):
+        def check(p):
+            if p.ndim != 2 or p.shape[1] != 2:
+                raise ValueError('Parameter perimeter has not the good shape.')
+            if p.shape[0] < 3:
+                raise ValueError('Parameter perimeter has not enough points.')
+        self._check_polygon_param('perimeter', [[0, 0], [0, 1], [1, 1], [1, 0]], check)
+
+    def _check_perspective(self):
+        def check(p):
+            if p.shape != (4, 2):
+                raise ValueError('Parameter perspective has not the good shape.')
+        self._check_polygon_param('perspective',
+                                  [[0.1, 0.4], [0.2, 0.8], [0.8, 0.2], [0.85, 0.3]], check)
+
+    # ---------------------------------------------------------------- detect
+    def detect(self, X):
+        """True if an intrusion is detected in frame X (reference pipeline.py:434-493)."""
+        if not self.input_shape_:
+            self.input_shape_ = X.shape
+            self._calib_first_frame()
+        elif X.shape != self.input_shape_:
+            raise ValueError('Input shape has changed.')
+
+        if self.convert:
+            X = cv.cvtColor(X, self.convert)
+
+        # steps 1-3 on the GPU
+        self.foreground_mask_ = self._foreground(X)
+
+        # steps 4-7 on the host
+        self._find_blob()
+        self._track_blob()
+        self._post_filter()
+        return self._maintain_alarm(self._detect_blob())
+
+    def _fusable(self):
+        """(blur, detector, morph) arguments of a ForegroundPipeline, or None when
+        the configuration contains callables that are not this package's."""
+        if self.blur:
+            if self.blur.get('fun') is not cv.GaussianBlur:
+                return None
+            kw, kh = self.blur.get('ksize')
+            # reference call convention: borderType arrives as sigmaX (pipeline.py:463-467)
+            blur = (int(kw), int(kh), float(self.blur.get('borderType')))
+            if kw < 1 or kh < 1 or kw % 2 == 0 or kh % 2 == 0:
+                return None
+        else:
+            blur = None
+        if self.frg_detect not in ('MOG2', 'FD'):
+            return None
+        morph = []
+        for d in self.mat_morph or []:
+            if d.get('fun') is cv.erode:
+                morph.append(('erode', d.get('kernel')))
+            elif d.get('fun') is cv.dilate:
+                morph.append(('dilate', d.get('kernel')))
+            else:
+                return None
+        return blur, self.frg_detect, morph
+
+    def _foreground(self, X):
+        if not self._fused_checked:
+            self._fused_checked = True
+            args = self._fusable()
+            if args is not None:
+                shape = X.shape if X.ndim == 3 else (X.shape[0], X.shape[1], 1)
+                try:
+                    self._fused = ForegroundPipeline(
+                        shape, streams=1, blur=args[0], detector=args[1], morph=args[2],
+                        fd_threshold=getattr(self._frg_detect_mth, 'threshold', 5))
+                except ValueError:
+                    self._fused = None      # e.g. kernel larger than the fused path takes
+        if self._fused is not None:
+            return self._fused.apply(X)
+        # generic path: the reference's own call sequence
+        if self.blur:
+            X = self.blur.get('fun')(X, self.blur.get('ksize'), self.blur.get('borderType'))
+        mask = self._frg_detect_mth.apply(X)
+        if self.mat_morph:
+            for d in self.mat_morph:
+                mask = d.get('fun')(mask, d.get('kernel'))
+        return mask
+
+    # ----------------------------------------------------------- calibration
+    def _calib_first_frame(self):
+        self.post_filter['perimeter'] = unnormalize_coords(
+            self.post_filter['perimeter'], self.input_shape_, dtype=np.int32)
+        self.post_filter['perspective'] = unnormalize_coords(
+            self.post_filter['perspective'], self.input_shape_, dtype=np.float64)
+        self._calib_perspective()
+
+    def _calib_perspective(self):
+        """Area / height / width of a person as linear functions of the row of its
+        bottom point, from the two reference boxes (reference pipeline.py:513-547)."""
+        (x0, y0), (x1, y1), (x2, y2), (x3, y3) = self.post_filter['perspective']
+        bottoms = [np.max([y1, y0]), np.max([y3, y2])]
+        rows = np.arange(0, self.input_shape_[0], 1)
+        samples = {
+            'area': [abs((y1 - y0) * (x1 - x0)), abs((y3 - y2) * (x3 - x2))],
+            'height': [abs(y1 - y0), abs(y3 - y2)],
+            'width': [abs(x1 - x0), abs(x3 - x2)],
+        }
+        slr = SimpleLinearRegression()
+        self._perspective = {key: slr.fit(bottoms, val).predict_clip(rows, 0)
+                             for key, val in samples.items()}
+
+    def _predict_perspective(self, key, y):
+        y = np.clip(y, a_min=0, a_max=self.input_shape_[0] - 1)
+        return self._perspective.get(key)[y]
+
+    # ----------------------------------------------------------------- blobs
+    def _find_blob(self, area_min=100):
+        contours = [c for c in find_contours(self.foreground_mask_)
+                    if hostcv.contourArea(c) >= area_min]
+        self.blobs_ = [self._create_blob(c) for c in contours]
+
+    def _create_blob(self, contour):
+        bottom = get_bottom(contour, dtype=np.int16)
+        center = get_center(contour, dtype=np.int16)
+        anchor = bottom if self.post_filter['anchor'] == 'bottom' else center
+        return {'contour': contour, 'anchor': anchor, 'bottom': bottom, 'center': center}
+
+    # -------------------------------------------------------------- tracking
+    def _track_blob(self):
+        """Greedy nearest-centre pairing inside an elliptic gate (reference :590-628)."""
+        n_tracked, n_blobs = len(self.tracked_blobs_), len(self.blobs_)
+        if n_tracked == 0:
+            self.tracked_blobs_.extend(self._create_tracked_blob(i) for i in range(n_blobs))
+            return
+        if n_blobs == 0:
+            for j in reversed(range(n_tracked)):
+                self._update_unpaired_tracked_blob(j)
+            return
+
+        dist = np.zeros((n_blobs, n_tracked))
+        for i in range(n_blobs):
+            for j in range(n_tracked):
+                dist[i, j] = self._compute_tracking_distance(j, i)
+
+        for i in range(n_blobs):
+            j_min = np.argmin(dist[i])
+            if dist[i, j_min] <= 1:
+                dist[i, j_min] = -1          # mark the pair
+                self._update_paired_tracked_blob(j_min, i)
+            else:
+                self.tracked_blobs_.append(self._create_tracked_blob(i))
+
+        for j in reversed(range(n_tracked)):
+            if np.all(dist[:, j] >= 0):
+                self._update_unpaired_tracked_blob(j)
+
+    def _create_tracked_blob(self, i_blob):
+        blob = self.blobs_[i_blob]
+        return {
+            'contour': blob['contour'].copy(), 'anchor': blob['anchor'], 'bottom': blob['bottom'],
+            'center': blob['center'], 'center_first': blob['center'], 'presence': 1, 'absence': 0,
+            'filtered': set(['presence', 'distance']), 'already_in_alarm': False,
+        }
+
+    def _compute_tracking_distance(self, i_tracked_blob, i_blob):
+        tracked = self.tracked_blobs_[i_tracked_blob]
+        radius_maj, radius_min = self._compute_tracking_space(tracked['bottom'])
+        if radius_maj <= 0 or radius_min <= 0:
+            return 0
+        delta = self.blobs_[i_blob]['center'] - tracked['center']   # int16, as the reference
+        return delta[0]**2 / radius_maj**2 + delta[1]**2 / radius_min**2
+
+    def _compute_tracking_space(self, bottom):
+        height_min = self._predict_perspective('height', bottom[1])
+        radius_major = np.int32(height_min * self.tracking['factor'])
+        radius_minor = np.int32(radius_major / 2)
+        return radius_major, radius_minor
+
+    def _update_paired_tracked_blob(self, i_tracked_blob, i_blob):
+        tracked, blob = self.tracked_blobs_[i_tracked_blob], self.blobs_[i_blob]
+        tracked['contour'] = blob['contour'].copy()
+        for key in ('anchor', 'bottom', 'center'):
+            tracked[key] = blob[key]
+        tracked['absence'] = 0
+        tracked['presence'] += 1
+        if tracked['presence'] >= self.post_filter['presence_min']:
+            tracked['filtered'].discard('presence')
+        if self._compute_total_distance(i_tracked_blob) >= self.post_filter['distance_min']:
+            tracked['filtered'].discard('distance')
+
+    def _compute_total_distance(self, i_tracked_blob):
+        tracked = self.tracked_blobs_[i_tracked_blob]
+        dist = hostcv.norm(tracked['center'] - tracked['center_first'])
+        area_min = self._predict_perspective('area', tracked['bottom'][1])
+        if area_min <= 0:
+            return 0
+        return dist / np.sqrt(area_min)
+
+    def _update_unpaired_tracked_blob(self, i_tracked_blob):
+        tracked = self.tracked_blobs_[i_tracked_blob]
+        tracked['presence'] = 0
+        tracked['filtered'].add('presence')
+        tracked['absence'] += 1
+        if tracked['absence'] >= self.tracking['absence_max']:
+            self.tracked_blobs_.pop(i_tracked_blob)
+
+    # ----------------------------------------------------------- post-filter
+    def _post_filter(self):
+        for tracked in self.tracked_blobs_:
+            inside = hostcv.pointPolygonTest(self.post_filter['perimeter'], tracked['anchor'],
+                                             False) >= 0
+            (tracked['filtered'].discard if inside else tracked['filtered'].add)('perimeter')
+
+            _, _, width, height = hostcv.boundingRect(tracked['contour'])
+            area_persp = self._predict_perspective('area', tracked['bottom'][1])
+            big_enough = width * height > area_persp * self.post_filter['perspective_coeff']
+            (tracked['filtered'].discard if big_enough else tracked['filtered'].add)('perspective')
+
+    def _detect_blob(self):
+        blob_in_alarm = False
+        for tracked in self.tracked_blobs_:
+            if tracked['filtered'] == set():
+                blob_in_alarm = True
+                if self.alarm_def['keep_alarm']:
+                    tracked['already_in_alarm'] = True
+            elif tracked['already_in_alarm']:
+                blob_in_alarm = True
+        return blob_in_alarm
+
+    def _maintain_alarm(self, sys_in_alarm):
+        state = self._alarm_system
+        state['duration'] -= 1
+        if sys_in_alarm and not state['already_in_alarm']:
+            state['duration'] = self.alarm_def['duration_min']     # beginning of an intrusion
+        if not sys_in_alarm and state['duration'] >= 0:
+            sys_in_alarm = True
+        if self.verbose and sys_in_alarm and not state['already_in_alarm']:
+            print("Intrusion detected")
+        state['already_in_alarm'] = sys_in_alarm
+        return sys_in_alarm
+
+    # --------------------------------------------------------------- display
+    def display(self, X, display={'tracking': False, 'perspective': False}):
+        """Draw perimeter, blobs and (optionally) tracking / perspective gates on X,
+        in place (reference pipeline.py:801-853)."""
+        hostcv.drawContours(X, [self.post_filter['perimeter']], 0, (25, 200, 200))
+        for tracked in self.tracked_blobs_:
+            flt = tracked['filtered']
+            if flt == set() or tracked['already_in_alarm']:
+                color = (0, 0, 255)
+            elif 'perimeter' in flt:
+                color = (255, 0, 0)
+            elif 'perspective' in flt:
+                color = (25, 200, 200)
+            elif 'presence' in flt or 'distance' in flt:
+                color = (0, 255, 0)
+            else:
+                raise ValueError(f'Unknown filtering type {flt}')
+            hostcv.drawContours(X, [tracked['contour']], 0, color)
+            hostcv.circle(X, tracked['anchor'], 4, color, -1)
+            if display.get('tracking'):
+                r_maj, r_min = self._compute_tracking_space(tracked['bottom'])
+                hostcv.ellipse(X, tracked['center'], [r_maj, r_min], 0, 0, 360, color, 1)
+            if display.get('perspective'):
+                bottom = tracked['bottom']
+                height = np.int32(self._predict_perspective('height', bottom[1]))
+                width = np.int32(self._predict_perspective('width', bottom[1]))
+                hostcv.rectangle(X, [bottom[0] - width // 2, bottom[1]],
+                                 [bottom[0] + width // 2, bottom[1] - height], color, 1)
+
+
+__all__ = ['GOFPID']

@@ -1,0 +1,170 @@
+"""CPU tests of the host logic around the GPU path: contour glue, geometry
+helpers, and GOFPID.initialize() error behaviour (mirrors the reference's
+tests/test_pipeline.py error cases and tests/test_helpers.py values)."""
+import numpy as np
+import pytest
+
+from pygofpid_amd import cv, hostcv
+from pygofpid_amd.helpers import (SimpleLinearRegression, find_contours, get_bottom, get_center,
+                                  normalize_coords, unnormalize_coords)
+from pygofpid_amd.pipeline import GOFPID
+
+perimeter = np.array([[0, 0], [0, 1], [1, 1], [1, 0]])
+perspective = np.array([[0.6, 0.5], [0.5, 0.8], [0.7, 0.2], [0.7, 0.3]])
+post_filter = {'perimeter': perimeter, 'anchor': 'center', 'perspective': perspective,
+               'perspective_coeff': 0.5, 'presence_min': 3, 'distance_min': 0.25}
+
+
+# ---- contours ---------------------------------------------------------------
+
+def test_find_contours_rectangles():
+    m = np.zeros((40, 60), np.uint8)
+    m[5:15, 10:30] = 255          # 10 x 20 block
+    m[20:35, 40:50] = 127         # grey levels count as foreground
+    cs = find_contours(m)
+    assert len(cs) == 2
+    cs = sorted(cs, key=lambda c: c[:, 0, 1].min())
+    a, b = cs
+    assert a.shape[1:] == (1, 2) and a.dtype == np.int32
+    assert hostcv.boundingRect(a) == (10, 5, 20, 10)
+    assert hostcv.boundingRect(b) == (40, 20, 10, 15)
+    assert hostcv.contourArea(a) == 19 * 9          # polygon through pixel centres
+    assert len(a) == 2 * (20 + 10) - 4              # every border pixel once
+    assert a[0, 0].tolist() == [10, 5]              # starts at the raster-first pixel
+    # square from the reference's tests/test_helpers.py: centre and bottom
+    sq = np.array([[[10, 10]], [[10, 20]], [[20, 20]], [[20, 10]]], np.int32)
+    assert get_center(sq).tolist() == [15, 15]
+    assert get_bottom(sq).tolist() == [15, 20]
+
+
+def test_find_contours_external_only_and_shapes():
+    m = np.zeros((30, 30), np.uint8)
+    m[2:28, 2:28] = 255
+    m[6:24, 6:24] = 0             # ring
+    m[10:20, 10:20] = 255         # island inside the hole: not external
+    cs = find_contours(m)
+    assert len(cs) == 1
+    assert hostcv.boundingRect(cs[0]) == (2, 2, 26, 26)
+    # single pixel, a 1-px line, diagonal 8-connectivity, touching the image border
+    m = np.zeros((12, 12), np.uint8)
+    m[1, 1] = 1
+    m[5, 2:9] = 1
+    m[8, 8] = m[9, 9] = m[10, 10] = 1
+    m[0, 6:12] = 1
+    cs = find_contours(m)
+    assert len(cs) == 4
+    by_box = {hostcv.boundingRect(c): c for c in cs}
+    assert (1, 1, 1, 1) in by_box and len(by_box[(1, 1, 1, 1)]) == 1
+    assert (2, 5, 7, 1) in by_box and len(by_box[(2, 5, 7, 1)]) == 12   # there and back
+    assert (8, 8, 3, 3) in by_box
+    assert (6, 0, 6, 1) in by_box
+    assert find_contours(np.zeros((5, 5), np.uint8)) == ()
+    assert len(find_contours(np.full((5, 7), 255, np.uint8))) == 1
+
+
+def test_find_contours_random_matches_scipy_components():
+    """One external contour per 8-connected component that touches the outside."""
+    from scipy import ndimage
+    rng = np.random.default_rng(3)
+    for _ in range(10):
+        m = (rng.random((40, 50)) > 0.62).astype(np.uint8) * 255
+        lab, n = ndimage.label(m, structure=np.ones((3, 3)))
+        # outside background: 4-connected zero region reachable from a 1-px frame
+        pad = np.pad(m == 0, 1, constant_values=True)
+        bl, _ = ndimage.label(pad)
+        outside = bl == bl[0, 0]
+        touch = ndimage.binary_dilation(outside, structure=ndimage.generate_binary_structure(2, 1))[1:-1, 1:-1]
+        external = {lab[y, x] for y, x in zip(*np.nonzero(touch & (m != 0)))}
+        cs = find_contours(m)
+        assert len(cs) == len(external)
+        for c in cs:
+            ids = {lab[y, x] for x, y in c[:, 0]}
+            assert len(ids) == 1 and ids.pop() in external
+            x, y, w, h = hostcv.boundingRect(c)
+            comp = np.nonzero(lab == lab[c[0, 0, 1], c[0, 0, 0]])
+            assert (x, y, w, h) == (comp[1].min(), comp[0].min(), np.ptp(comp[1]) + 1, np.ptp(comp[0]) + 1)
+
+
+def test_polygon_tests_and_moments():
+    sq = np.array([[0, 0], [0, 10], [10, 10], [10, 0]])
+    assert hostcv.pointPolygonTest(sq, (5, 5)) == 1
+    assert hostcv.pointPolygonTest(sq, (0, 5)) == 0
+    assert hostcv.pointPolygonTest(sq, (10, 10)) == 0
+    assert hostcv.pointPolygonTest(sq, (11, 5)) == -1
+    assert hostcv.pointPolygonTest(sq, np.array([5, -1], np.int16)) == -1
+    m = hostcv.moments(sq.reshape(-1, 1, 2))
+    assert m["m00"] == 100 and m["m10"] / m["m00"] == 5 and m["m01"] / m["m00"] == 5
+    assert hostcv.moments(sq[::-1].reshape(-1, 1, 2))["m00"] == 100      # orientation-free
+    assert hostcv.contourArea(sq.reshape(-1, 1, 2)) == 100
+    assert hostcv.norm(np.array([3, 4], np.int16)) == 5
+
+
+def test_coords_and_regression():
+    c = unnormalize_coords(np.array([[0.5, 0.5], [1.0, 0.25]]), (100, 200), dtype=np.int32)
+    assert c.tolist() == [[100, 50], [200, 25]]
+    n = normalize_coords([[100, 50]], (100, 200))
+    assert n.tolist() == [[0.5, 0.5]]
+    src = np.array([[0.5, 0.5]])
+    unnormalize_coords(src, (10, 10))
+    assert src.tolist() == [[0.5, 0.5]]                    # caller's array untouched
+    slr = SimpleLinearRegression().fit([0, 10], [5, 25])
+    assert (slr.coeff, slr.intercept) == (2, 5)
+    assert slr.predict_clip([-10, 0, 20], 0, 30).tolist() == [0, 5, 30]
+    with pytest.raises(ValueError):
+        slr.fit([1, 2, 3], [1, 2, 3])
+
+
+# ---- GOFPID.initialize(): the reference's error contract --------------------
+
+def test_gofpid_defaults_are_not_shared():
+    a, b = GOFPID(), GOFPID()
+    assert a.blur is not b.blur and a.mat_morph is not b.mat_morph
+    assert a.post_filter is not b.post_filter
+    assert a.blur['fun'] is cv.GaussianBlur and a.blur['borderType'] == cv.BORDER_DEFAULT
+    assert [d['fun'] for d in a.mat_morph] == [cv.erode, cv.dilate]
+    assert a.mat_morph[0]['kernel'].shape == (5, 5)
+    g = a.initialize()
+    assert g is a and g.tracked_blobs_ == [] and g.input_shape_ is None
+
+
+def test_gofpid_blur_and_morph_errors():
+    with pytest.raises(KeyError):           # reference tests/test_pipeline.py:89-95
+        GOFPID(blur={'ksize': (3, 3)}, post_filter=post_filter.copy()).initialize()
+    with pytest.raises(KeyError):           # :149-158
+        GOFPID(mat_morph=[{'kernel': cv.getStructuringElement(cv.MORPH_RECT, (5, 5))}],
+               post_filter=post_filter.copy()).initialize()
+    with pytest.raises(ValueError):         # :112-118
+        GOFPID(frg_detect='blabla', post_filter=post_filter.copy()).initialize()
+    with pytest.raises(KeyError):           # :161-166
+        GOFPID(tracking={'blabla': 42}, post_filter=post_filter.copy()).initialize()
+    g = GOFPID(blur={'fun': cv.GaussianBlur}, mat_morph=[{'fun': cv.erode}],
+               post_filter=post_filter.copy()).initialize()
+    assert g.blur['ksize'] == (3, 3) and g.blur['borderType'] == cv.BORDER_DEFAULT
+    assert g.mat_morph[0]['kernel'].shape == (5, 5)
+    for name in ('KNN', 'ViBe'):
+        with pytest.raises(NotImplementedError):
+            GOFPID(frg_detect=name, post_filter=post_filter.copy()).initialize()
+
+
+@pytest.mark.parametrize("drop_or_set", [
+    ('drop', 'perimeter'), ('set', 'perimeter', np.array([[1, 5], [3, 9]])), ('drop', 'anchor'),
+    ('set', 'anchor', 'blabla'), ('drop', 'perspective'),
+    ('set', 'perspective', np.array([[1, 5, 2], [3, 9, 4]])), ('drop', 'perspective_coeff'),
+    ('drop', 'presence_min'), ('drop', 'distance_min'), ('set', 'perimeter', [[0, 0], [1, 1], [1, 0]]),
+])
+def test_gofpid_postfilter_errors(drop_or_set):
+    """reference tests/test_pipeline.py:188-264"""
+    pf = post_filter.copy()
+    if drop_or_set[0] == 'drop':
+        del pf[drop_or_set[1]]
+    else:
+        pf[drop_or_set[1]] = drop_or_set[2]
+    with pytest.raises((KeyError, ValueError)):
+        GOFPID(post_filter=pf).initialize()
+
+
+def test_gofpid_alarmdef_errors_and_headless():
+    with pytest.raises(KeyError):
+        GOFPID(alarm_def={'keep_alarm': True}).initialize()
+    with pytest.raises(NotImplementedError):
+        GOFPID(post_filter=dict(post_filter, display_config=True)).initialize()
