@@ -116,9 +116,9 @@ def main():
     args = ap.parse_args()
 
     import torch
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+
+    from pygofpid_amd import distributed as gd
+    rank, world, local = gd.env_rank()
     if args.gpus != world and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if args.gpus > 1 and world == 1:
@@ -127,10 +127,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    gd.init(backend="nccl", device=device)   # no-op for a single process
 
     from pygofpid_amd import _lib
     from pygofpid_amd.foreground import ForegroundPipeline
@@ -147,8 +144,7 @@ def main():
     def barrier():
         pipe.synchronize()
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        gd.barrier()
 
     for t in range(W):
         pipe.apply_device(frames[t % P].data_ptr(), masks.data_ptr())
@@ -162,13 +158,8 @@ def main():
         pipe.apply_device(frames[t % P].data_ptr(), masks.data_ptr())
     pipe.synchronize()
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        el = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        elapsed = float(el.item())
+    gd.barrier()
+    elapsed = gd.max_over_ranks(time.perf_counter() - t0, device=device)
 
     det_ms = morph_ms = 0.0
     n_meas = 0
@@ -226,8 +217,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(host, h, w, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        gd.barrier()
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

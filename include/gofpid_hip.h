@@ -143,6 +143,9 @@ int gof_mog2_import(gof_mog2 *m, const float *weight, const float *var, const fl
 /* raw device view of the same planes (one allocation) for an RCCL broadcast */
 int gof_mog2_device_state(gof_mog2 *m, void **d_state, size_t *bytes);
 int gof_mog2_set_nframes(gof_mog2 *m, int nframes);
+/* copy the whole model to (to_model == 0) or from (to_model != 0) a caller-owned
+ * device buffer of gof_mog2_device_state()'s size; synchronous */
+int gof_mog2_state_copy(gof_mog2 *m, void *d_buf, int to_model);
 
 /* ---- step 2b: frame differencing (replaces FrameDifferencing.apply,
  *      segmentation.py:40-70) ---------------------------------------------- */

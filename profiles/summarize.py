@@ -56,10 +56,12 @@ def main(d):
             # reports 1/2 of the bytes of a wide coalesced streaming read -> x2.
             fetch_raw = cs["FETCH_SIZE"] * 1024.0
             write = cs["WRITE_SIZE"] * 1024.0
-            rec = {"kernel": k, "fetch_size_raw_bytes": fetch_raw, "fetch_bytes_corrected": 2 * fetch_raw,
+            rec = {"config": {"streams": 8, "height": 1080, "width": 1920},   # bench.py defaults
+                   "kernel": k, "fetch_size_raw_bytes": fetch_raw, "fetch_bytes_corrected": 2 * fetch_raw,
                    "write_bytes": write, "hbm_bytes_per_launch": 2 * fetch_raw + write,
-                   "note": "FETCH_SIZE x2 per MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B); "
-                           "the x2 is calibrated for 16-B/lane streams, this kernel issues 4-B/lane loads"}
+                   "note": "per launch, mean of the last half of the dispatches; FETCH_SIZE x2 per "
+                           "MI355X_MICROARCH.md (gfx950 tallies 128-B requests as 64 B), factor "
+                           "re-calibrated for 4-B/lane streams in profiles/r01_counter_calibration.txt"}
             print("\ntraffic:", json.dumps(rec))
             with open(os.path.join(d, "traffic.json"), "w") as f:
                 json.dump(rec, f)

@@ -80,6 +80,7 @@ SIGNATURES = {
     "gof_mog2_import": (C.c_int, [C.c_void_p, _f32p, _f32p, _f32p, _u8p, C.c_int]),
     "gof_mog2_device_state": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p),
                                         C.POINTER(C.c_size_t)]),
+    "gof_mog2_state_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "gof_fd_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
                                 C.POINTER(C.c_void_p)]),
     "gof_fd_destroy": (None, [C.c_void_p]),

@@ -592,6 +592,20 @@ int gof_mog2_device_state(gof_mog2 *m, void **d_state, size_t *bytes)
     return GOF_OK;
 }
 
+int gof_mog2_state_copy(gof_mog2 *m, void *d_buf, int to_model)
+{
+    if (!m || !d_buf)
+        return fail(GOF_EINVAL, "NULL argument");
+    GOF_HIP(hipSetDevice(m->ctx->device));
+    hipStream_t s = m->ctx->stream;
+    if (to_model)
+        GOF_HIP(hipMemcpyAsync(m->state, d_buf, m->state_bytes, hipMemcpyDeviceToDevice, s));
+    else
+        GOF_HIP(hipMemcpyAsync(d_buf, m->state, m->state_bytes, hipMemcpyDeviceToDevice, s));
+    GOF_HIP(hipStreamSynchronize(s));
+    return GOF_OK;
+}
+
 /* ---- frame differencing -------------------------------------------------- */
 
 int gof_fd_create(gof_ctx *ctx, int streams, int h, int w, int c, double threshold, gof_fd **out)

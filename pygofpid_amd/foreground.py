@@ -147,6 +147,20 @@ class ForegroundPipeline:
         _lib.check(_lib.load().gof_mog2_device_state(m, C.byref(p), C.byref(n)))
         return p.value, n.value
 
+    def state_to_buffer(self, device_ptr):
+        """Copy the whole model into a caller-owned device buffer (mog2_device_state()[1] bytes)."""
+        m = _lib.load().gof_pipeline_mog2(self._h)
+        _lib.check(_lib.load().gof_mog2_state_copy(m, C.c_void_p(device_ptr), 0))
+
+    def state_from_buffer(self, device_ptr, nframes):
+        m = _lib.load().gof_pipeline_mog2(self._h)
+        _lib.check(_lib.load().gof_mog2_state_copy(m, C.c_void_p(device_ptr), 1))
+        self.set_nframes(nframes)
+
+    def nframes(self):
+        m = _lib.load().gof_pipeline_mog2(self._h)
+        return _lib.load().gof_mog2_nframes(m) if m else 0
+
     def set_nframes(self, nframes):
         m = _lib.load().gof_pipeline_mog2(self._h)
         if m:
