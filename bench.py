@@ -30,6 +30,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# the CPU leg is a throughput run: let the OpenMP workers spin between the
+# per-frame parallel regions (read by libgomp when oracle/ is loaded)
+os.environ.setdefault("OMP_WAIT_POLICY", "active")
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
@@ -66,24 +69,33 @@ def make_pool(torch, streams, pool, h, w, device, seed):
 
 
 def cpu_baseline(frames_host, h, w, budget_s):
-    """Time the CPU oracle on this host (checker reused as the baseline leg)."""
+    """Time the CPU oracle on this host (checker reused as the baseline leg).
+    The thread count is the best of a short sweep up to the CPUs this process
+    may use; `cores` reports the count actually used for the timed sample."""
     from oracle import cpu as oracle
     oracle.build()
-    p = oracle.Pipeline(h, w, 3)
     n = len(frames_host)
-    for i in range(min(8, n)):          # page in + first-frame model creation
-        p.apply(frames_host[i % n])
-    done, t0 = 0, time.perf_counter()
-    while True:
-        p.apply(frames_host[done % n])
-        done += 1
-        el = time.perf_counter() - t0
-        if el >= budget_s or done >= 2048:
-            break
-    return {"value": round(done / el, 2), "unit": "frames/s", "cores": p.threads, "kind": "port",
-            "sample": "%d frames of 1 stream %dx%d BGR in %.1f s, OpenMP row bands over %d threads; "
-                      "OpenCV-algorithm CPU restatement (oracle/gof_oracle.c), not OpenCV"
-                      % (done, w, h, el, p.threads),
+    budget = oracle.cpu_budget()
+    cands = sorted({t for t in (8, 16, 32, 64, 96, 128, budget) if t <= budget} or {1})
+
+    def rate(threads, seconds, warm):
+        p = oracle.Pipeline(h, w, 3, threads=threads)
+        for i in range(warm):
+            p.apply(frames_host[i % n])
+        done, t0 = 0, time.perf_counter()
+        while True:
+            p.apply(frames_host[done % n])
+            done += 1
+            el = time.perf_counter() - t0
+            if el >= seconds or done >= 4096:
+                return done / el, done, el, p
+
+    best = max(cands, key=lambda t: rate(t, 0.6, 4)[0]) if len(cands) > 1 else cands[0]
+    fps, done, el, p = rate(best, budget_s, 8)
+    return {"value": round(fps, 2), "unit": "frames/s", "cores": best, "kind": "port",
+            "sample": "%d frames of 1 stream %dx%d BGR in %.1f s, OpenMP row bands over %d threads "
+                      "(best of %s on a %d-CPU budget); OpenCV-algorithm CPU restatement "
+                      "(oracle/gof_oracle.c), not OpenCV" % (done, w, h, el, best, cands, budget),
             "mean_modes": round(p.mean_modes(), 4)}
 
 
