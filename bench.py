@@ -165,6 +165,8 @@ def main():
     if not args.no_events:
         pipe.profile(True, K)
     barrier()
+    if os.environ.get("GOF_ABLATE_TIMED"):          # profiles/ ablations: flip after the warm-up
+        os.environ["GOF_ABLATE"] = os.environ["GOF_ABLATE_TIMED"]
     t0 = time.perf_counter()
     for t in range(W, W + K):
         pipe.apply_device(frames[t % P].data_ptr(), masks.data_ptr())

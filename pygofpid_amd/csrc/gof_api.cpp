@@ -9,6 +9,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -454,6 +455,8 @@ int gof_mog2_create(gof_ctx *ctx, int streams, int h, int w, int c, const gof_mo
     m->c = c;
     size_t n = (size_t)streams * h * w;
     m->np = (n + 63) & ~(size_t)63;   // planes start on 256-B boundaries
+    if (const char *e = getenv("GOF_PITCH_PAD"))   // tuning knob: extra floats of plane pitch
+        m->np += (size_t)(atoi(e) > 0 ? atoi(e) : 0) & ~(size_t)63;
     m->state_bytes = (size_t)pp.nmixtures * (2 + c) * m->np * sizeof(float) + m->np;
     GOF_HIP(hipSetDevice(ctx->device));
     hipError_t e = hipMalloc(&m->state, m->state_bytes);
@@ -728,7 +731,7 @@ int gof_morph_dev(gof_ctx *ctx, int op, const void *d_src, void *d_dst, int n_im
         ch.ry[0] = kh / 2;
         if (gofk::morph_rect_chain_supported(ch)) {
             GOF_HIP(gofk::morph_rect_chain((const uint8_t *)d_src, (uint8_t *)d_dst, n_images, h, w,
-                                           ch, s));
+                                           ch, false, s));   // arbitrary grey levels
             return GOF_OK;
         }
     }
@@ -894,8 +897,9 @@ int gof_pipeline_apply_dev(gof_pipeline *p, const void *d_frames, void *d_masks,
     // step 3 (pipeline.py:473-475)
     if (d.n_morph > 0) {
         if (p->chain_ok) {
+            // detector masks are chain-valued ({0, shadow, 255} / {0, 84, 85} / {0, 255})
             GOF_HIP(gofk::morph_rect_chain(det_out, (uint8_t *)d_masks, d.streams, d.h, d.w,
-                                           p->chain, s));
+                                           p->chain, true, s));
         } else {
             if (d.n_morph > 1 && (rc = p->m1.reserve(npx)))
                 return rc;

@@ -63,9 +63,11 @@ hipError_t fd_apply(const uint8_t *cur, const uint8_t *prev, bool has_prev, int 
 hipError_t morph_generic(int op, const uint8_t *src, uint8_t *dst, int n_img, int h, int w,
                          const SeBits &se, hipStream_t s);
 
-// all ops rectangular with odd sizes: one kernel, intermediates stay in LDS.
+// all ops rectangular with odd sizes: one kernel, intermediates stay on chip.
+// chain_valued: the caller guarantees that the mask's values form a chain under
+// bitwise inclusion (every mask MOG2 / FD produce does) -> AND/OR fast path.
 hipError_t morph_rect_chain(const uint8_t *src, uint8_t *dst, int n_img, int h, int w,
-                            const RectChain &ch, hipStream_t s);
+                            const RectChain &ch, bool chain_valued, hipStream_t s);
 bool morph_rect_chain_supported(const RectChain &ch);
 
 // (h,w,c in {3,4}) -> (h,w) luma, BGR order unless rgb

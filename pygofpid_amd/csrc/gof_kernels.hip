@@ -10,6 +10,7 @@
 #include "gof_kernels.h"
 
 #include <float.h>
+#include <stdlib.h>
 
 namespace gofk {
 
@@ -74,17 +75,25 @@ __device__ __forceinline__ void swap_modes(PixelModel<C> &M, int i, bool doit)
 // re-statement is that the fitted mode's new weight is stored in its slot
 // BEFORE it is bubbled up, so that it travels with the swaps (OpenCV swaps
 // first and then writes gmm[mode - swap_count].weight: same end state).
-template <int C>
+//
+// MAXIN is a compile-time upper bound of the mode count on entry.  The kernel
+// calls the MAXIN = 1 instance when no pixel of the wave has a second mode
+// (four waves out of five on surveillance footage): same statements, same
+// order, same results, but only the slots that can be live (0 on entry, 0..1 on
+// exit) are ever touched, which removes most of the unrolled predication.
+template <int C, int MAXIN>
 __device__ __forceinline__ uint8_t mog2_update(PixelModel<C> &M, int &nmodes_io, const float (&x)[C],
                                                const Mog2Consts &k)
 {
+    constexpr int LIN = MAXIN < kMaxModes ? MAXIN : kMaxModes;            // live slots on entry
+    constexpr int LOUT = MAXIN + 1 < kMaxModes ? MAXIN + 1 : kMaxModes;   // ... after an insertion
     int nmodes = nmodes_io;
     bool background = false, fits = false;
     float totalWeight = 0.f;
     const float negprune = -k.prune;
 
 #pragma unroll
-    for (int m = 0; m < kMaxModes; m++) {
+    for (int m = 0; m < LIN; m++) {
         if (m < nmodes) {  // live bound: nmodes shrinks when a mode is pruned
             float weight = k.alpha1 * M.w[m] + k.prune;
             bool fit_here = false;
@@ -143,7 +152,7 @@ __device__ __forceinline__ uint8_t mog2_update(PixelModel<C> &M, int &nmodes_io,
     if (fabsf(totalWeight) > FLT_EPSILON)
         inv = 1.f / totalWeight;
 #pragma unroll
-    for (int m = 0; m < kMaxModes; m++)
+    for (int m = 0; m < LIN; m++)
         if (m < nmodes)
             M.w[m] *= inv;
 
@@ -151,7 +160,7 @@ __device__ __forceinline__ uint8_t mog2_update(PixelModel<C> &M, int &nmodes_io,
         int slot = nmodes == k.nmix ? k.nmix - 1 : nmodes++;
         bool first = nmodes == 1;
 #pragma unroll
-        for (int m = 0; m < kMaxModes; m++) {
+        for (int m = 0; m < LOUT; m++) {
             if (m == slot) {
                 M.w[m] = first ? 1.f : k.alphaT;
                 M.var[m] = k.var_init;
@@ -164,7 +173,7 @@ __device__ __forceinline__ uint8_t mog2_update(PixelModel<C> &M, int &nmodes_io,
         }
         bool go = true;
 #pragma unroll
-        for (int i = kMaxModes - 1; i > 0; i--) {
+        for (int i = LOUT - 1; i > 0; i--) {
             bool in = i <= nmodes - 1;
             bool sw = in && go && !(k.alphaT < M.w[i - 1]);
             if (in)
@@ -181,7 +190,7 @@ __device__ __forceinline__ uint8_t mog2_update(PixelModel<C> &M, int &nmodes_io,
         float tW = 0.f;
         bool done = false;
 #pragma unroll
-        for (int m = 0; m < kMaxModes; m++) {
+        for (int m = 0; m < LOUT; m++) {
             if (!done && m < nmodes) {
                 float num = 0.f, den = 0.f;
 #pragma unroll
@@ -233,14 +242,36 @@ __global__ __launch_bounds__(256) void mog2_kernel(const uint8_t *__restrict__ f
                                                    float *__restrict__ planes,
                                                    uint8_t *__restrict__ modes, size_t np, int H,
                                                    int W, Mog2Consts k, uint32_t kx012,
-                                                   uint32_t ky012)
+                                                   uint32_t ky012, int xcd_swizzle)
 {
     constexpr int F = 2 + C;  // floats per mode
     const int lane = threadIdx.x & 63;
     // wave-uniform values are forced into SGPRs: row index, row bases, plane bases
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
-    const int img = blockIdx.z;
+    // XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs
+    // (b and b+8 share an L2).  Horizontally adjacent tiles share 128-B lines of
+    // the byte planes and of the frame rows, vertically adjacent ones share halo
+    // rows; giving each XCD one contiguous run of tiles keeps those lines in ONE
+    // L2 instead of fetching them from HBM once per XCD.  Speed only: any
+    // placement computes the same result.
+    const int tiles_x = (W + TW - 1) / TW;
+    const int ntiles = tiles_x * ((H + TH - 1) / TH);
+    // q = xcd_swizzle tiles in a row go to the SAME XCD (blocks b and b+8 share one);
+    // the 8 XCDs together still sweep 8q consecutive tiles, which keeps the DRAM
+    // pages they touch close together.
+    const int dbg = xcd_swizzle >> 8;   // profiles/ ablations only (GOF_ABLATE), 0 in production
+    xcd_swizzle &= 255;
+    int tidx = (int)blockIdx.x;
+    if (xcd_swizzle > 1) {
+        const int span = 8 * xcd_swizzle;
+        const int g = tidx / span, r = tidx - g * span;
+        tidx = g * span + (r & 7) * xcd_swizzle + (r >> 3);
+    }
+    if (tidx >= ntiles)
+        return;  // padding of the 1-D grid; whole workgroup, before any barrier
+    const int ty = tidx / tiles_x;
+    const int x0 = (tidx - ty * tiles_x) * TW, y0 = ty * TH;
+    const int img = blockIdx.y;
     const int x = x0 + lane, y = y0 + wave;
     const size_t N = (size_t)H * W;
     const uint8_t *fimg = frame + (size_t)img * N * C;
@@ -330,39 +361,72 @@ __global__ __launch_bounds__(256) void mog2_kernel(const uint8_t *__restrict__ f
     if (!valid)
         return;
 
-    // ---- remaining modes, predicated on the pixel's own mode count ----
+    // ---- wave-uniform split: does any pixel of this wave carry a second mode? ----
+    uint8_t out;
+    if (__builtin_amdgcn_ballot_w64(nmodes > 1) == 0) {
+        // single-mode wave: nothing more to load; at most slots 0..1 are live afterwards
 #pragma unroll
-    for (int m = 1; m < kMaxModes; m++) {
-        if (m < nmodes) {
-            const float *pm = prow + (size_t)m * F * np;
-            M.w[m] = pm[xl];
-            M.var[m] = (pm + np)[xl];
-#pragma unroll
-            for (int c = 0; c < C; c++)
-                M.mu[m][c] = (pm + (size_t)(2 + c) * np)[xl];
-        } else {
+        for (int m = 1; m < kMaxModes; m++) {
             M.w[m] = 0.f;
             M.var[m] = 0.f;
 #pragma unroll
             for (int c = 0; c < C; c++)
                 M.mu[m][c] = 0.f;
         }
-    }
-
-    uint8_t out = mog2_update<C>(M, nmodes, xin, k);
-
+        if (dbg & 1) {
+            out = (uint8_t)(xin[0] + M.w[0]);
+        } else {
+            out = mog2_update<C, 1>(M, nmodes, xin, k);
+        }
 #pragma unroll
-    for (int m = 0; m < kMaxModes; m++) {
-        if (m < nmodes) {
-            float *pm = prow + (size_t)m * F * np;
-            pm[xl] = M.w[m];
-            (pm + np)[xl] = M.var[m];
+        for (int m = 0; m < 2; m++) {
+            if (m < nmodes && !(dbg & 2)) {
+                float *pm = prow + (size_t)m * F * np;
+                pm[xl] = M.w[m];
+                (pm + np)[xl] = M.var[m];
 #pragma unroll
-            for (int c = 0; c < C; c++)
-                (pm + (size_t)(2 + c) * np)[xl] = M.mu[m][c];
+                for (int c = 0; c < C; c++)
+                    (pm + (size_t)(2 + c) * np)[xl] = M.mu[m][c];
+            }
+        }
+    } else {
+        // remaining modes, predicated on the pixel's own mode count
+#pragma unroll
+        for (int m = 1; m < kMaxModes; m++) {
+            if (m < nmodes) {
+                const float *pm = prow + (size_t)m * F * np;
+                M.w[m] = pm[xl];
+                M.var[m] = (pm + np)[xl];
+#pragma unroll
+                for (int c = 0; c < C; c++)
+                    M.mu[m][c] = (pm + (size_t)(2 + c) * np)[xl];
+            } else {
+                M.w[m] = 0.f;
+                M.var[m] = 0.f;
+#pragma unroll
+                for (int c = 0; c < C; c++)
+                    M.mu[m][c] = 0.f;
+            }
+        }
+        if (dbg & 1) {
+            out = (uint8_t)(xin[0] + M.w[0] + M.w[1] + M.w[2] + M.w[3] + M.w[4]);
+        } else {
+            out = mog2_update<C, kMaxModes>(M, nmodes, xin, k);
+        }
+#pragma unroll
+        for (int m = 0; m < kMaxModes; m++) {
+            if (m < nmodes && !(dbg & 2)) {
+                float *pm = prow + (size_t)m * F * np;
+                pm[xl] = M.w[m];
+                (pm + np)[xl] = M.var[m];
+#pragma unroll
+                for (int c = 0; c < C; c++)
+                    (pm + (size_t)(2 + c) * np)[xl] = M.mu[m][c];
+            }
         }
     }
-    modes[rowoff + xl] = (uint8_t)nmodes;
+    if (!(dbg & 4))
+        modes[rowoff + xl] = (uint8_t)nmodes;
     mask[rowoff + xl] = out;
 }
 
@@ -697,6 +761,330 @@ __global__ __launch_bounds__(256) void morph_chain_kernel(const uint8_t *__restr
 }
 
 // ---------------------------------------------------------------------------
+// register-streaming variant of the fused chain for the common small kernels
+// (every op rectangular with rx <= 4, ry <= 4: 3x3 ... 9x9).
+//
+// A wave owns a strip of 64 dwords = 256 px; lane l keeps its 4-px column of NR
+// consecutive rows in registers, split into even bytes E = (px0, px2) and odd
+// bytes O = (px1, px3) as two u16 pairs, so that a byte-wise min/max is one
+// v_pk_{min,max}_u16 per register with no unpacking inside the loops.
+//   row pass    : the neighbours' registers come over DPP wave shifts (no LDS);
+//                 a window shifted by s px is at most one v_alignbit per register.
+//   column pass : out[j] = op(in[j-ry .. j+ry]) over the register array, written
+//                 back at index j-ry (dead by then), so the whole chain runs in
+//                 place; RY is a template parameter to keep every index static.
+// Each op shrinks the valid region by one lane per side and ry rows per side;
+// out-of-image bytes are forced to the next op's identity after every op.
+// ---------------------------------------------------------------------------
+template <bool IS_MAX>
+__device__ __forceinline__ uint32_t pkmm(uint32_t a, uint32_t b)
+{
+    return pk16<IS_MAX>(a, b);
+}
+
+__device__ __forceinline__ uint32_t lane_prev(uint32_t v)   // value of lane-1 (lane 0: unchanged)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138 /*wave_shr:1*/, 0xF, 0xF, false);
+}
+__device__ __forceinline__ uint32_t lane_next(uint32_t v)   // value of lane+1 (lane 63: unchanged)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x130 /*wave_shl:1*/, 0xF, 0xF, false);
+}
+__device__ __forceinline__ uint32_t al16(uint32_t hi, uint32_t lo)   // (lo.hi16, hi.lo16)
+{
+    return __builtin_amdgcn_alignbit(hi, lo, 16);
+}
+
+template <int NR, bool IS_MAX, int RY>
+__device__ __forceinline__ void stream_op(uint32_t (&E)[NR], uint32_t (&O)[NR], int rx)
+{
+    // Straight-line over all NR register rows: rows past the still-valid range
+    // hold don't-care values (never stored), which is cheaper than guarding each
+    // row with a branch.
+    // ---- row pass ----
+#pragma unroll
+    for (int j = 0; j < NR; j++) {
+        {
+            const uint32_t e = E[j], o = O[j];
+            const uint32_t ep = lane_prev(e), en = lane_next(e), op = lane_prev(o), on = lane_next(o);
+            const uint32_t a1 = al16(en, e), a2 = al16(on, o), a3 = al16(e, ep), a4 = al16(o, op);
+            uint32_t re = e, ro = o;
+            if (rx >= 1) {   // +1: (o, a1)   -1: (a4, e)
+                re = pkmm<IS_MAX>(pkmm<IS_MAX>(re, o), a4);
+                ro = pkmm<IS_MAX>(pkmm<IS_MAX>(ro, a1), e);
+            }
+            if (rx >= 2) {   // +2: (a1, a2)  -2: (a3, a4)
+                re = pkmm<IS_MAX>(pkmm<IS_MAX>(re, a1), a3);
+                ro = pkmm<IS_MAX>(pkmm<IS_MAX>(ro, a2), a4);
+            }
+            if (rx >= 3) {   // +3: (a2, en)  -3: (op, a3)
+                re = pkmm<IS_MAX>(pkmm<IS_MAX>(re, a2), op);
+                ro = pkmm<IS_MAX>(pkmm<IS_MAX>(ro, en), a3);
+            }
+            if (rx >= 4) {   // +4: (en, on)  -4: (ep, op)
+                re = pkmm<IS_MAX>(pkmm<IS_MAX>(re, en), ep);
+                ro = pkmm<IS_MAX>(pkmm<IS_MAX>(ro, on), op);
+            }
+            E[j] = re;
+            O[j] = ro;
+        }
+    }
+    // ---- column pass: result row j (centre) is stored at index j - RY ----
+#pragma unroll
+    for (int j = RY; j < NR - RY; j++) {
+        {
+            uint32_t re = E[j - RY], ro = O[j - RY];
+#pragma unroll
+            for (int d = -RY + 1; d <= RY; d++) {
+                re = pkmm<IS_MAX>(re, E[j + d]);
+                ro = pkmm<IS_MAX>(ro, O[j + d]);
+            }
+            E[j - RY] = re;
+            O[j - RY] = ro;
+        }
+    }
+}
+
+// Bitwise form of the same op for masks whose values form a chain under bitwise
+// inclusion, a <= b  <=>  (a & b) == a.  Then min == AND and max == OR on whole
+// dwords: 4 px per instruction, no even/odd split.  Every mask a detector of
+// this library produces is such a chain: MOG2 {0, shadow_value, 255} (0 and 255
+// are below / above every byte), FD {0, 255}, {0, 84, 85} (BGR) or {0, 63} (4 ch).
+template <int NR, bool IS_MAX, int RY>
+__device__ __forceinline__ void stream_op_bits(uint32_t (&R)[NR], int rx)
+{
+#pragma unroll
+    for (int j = 0; j < NR; j++) {
+        const uint32_t r = R[j];
+        const uint32_t p = lane_prev(r), n = lane_next(r);
+        uint32_t acc = r;
+#define GOF_BW(x) acc = IS_MAX ? (acc | (x)) : (acc & (x))
+        if (rx >= 1) {
+            GOF_BW(__builtin_amdgcn_alignbyte(n, r, 1));
+            GOF_BW(__builtin_amdgcn_alignbyte(r, p, 3));
+        }
+        if (rx >= 2) {
+            GOF_BW(__builtin_amdgcn_alignbyte(n, r, 2));
+            GOF_BW(__builtin_amdgcn_alignbyte(r, p, 2));
+        }
+        if (rx >= 3) {
+            GOF_BW(__builtin_amdgcn_alignbyte(n, r, 3));
+            GOF_BW(__builtin_amdgcn_alignbyte(r, p, 1));
+        }
+        if (rx >= 4) {
+            GOF_BW(n);
+            GOF_BW(p);
+        }
+        R[j] = acc;
+    }
+#pragma unroll
+    for (int j = RY; j < NR - RY; j++) {
+        uint32_t acc = R[j - RY];
+#pragma unroll
+        for (int d = -RY + 1; d <= RY; d++)
+            GOF_BW(R[j + d]);
+        R[j - RY] = acc;
+    }
+#undef GOF_BW
+}
+
+template <int NR>
+__global__ __launch_bounds__(64) void morph_stream_bits_kernel(const uint8_t *__restrict__ src,
+                                                                uint8_t *__restrict__ dst, int H,
+                                                                int W, RectChain ch, int HQ, int RY)
+{
+    // dword-aligned images only (the launcher checks); same geometry as morph_stream_kernel
+    const int lane = threadIdx.x;
+    const int rows_out = NR - 2 * RY;
+    const int strip_px = (64 - 2 * HQ) * 4;
+    const int sx0 = blockIdx.x * strip_px;
+    const int y0 = blockIdx.y * rows_out;
+    if (sx0 >= W || y0 >= H)
+        return;
+    const size_t N = (size_t)H * W;
+    const uint8_t *simg = src + (size_t)blockIdx.z * N;
+    uint8_t *dimg = dst + (size_t)blockIdx.z * N;
+    const int gx0 = sx0 - 4 * HQ + 4 * lane;
+    const int Y0 = y0 - RY;
+    const uint32_t cm = (gx0 >= 0 && gx0 < W) ? 0xFFFFFFFFu : 0u;   // W % 4 == 0: all or nothing
+    // interior strips never see the border: skip the identity re-imposition there
+    const bool interior = __builtin_amdgcn_readfirstlane(
+        (int)(sx0 - 4 * HQ >= 0 && sx0 - 4 * HQ + 256 <= W && Y0 >= 0 && Y0 + NR <= H));
+
+    uint32_t R[NR];
+    const int gxc = gx0 < 0 ? 0 : (gx0 > W - 4 ? W - 4 : gx0);
+#pragma unroll
+    for (int j = 0; j < NR; j++) {
+        const int gy = Y0 + j;
+        const int gyc = gy < 0 ? 0 : (gy > H - 1 ? H - 1 : gy);
+        R[j] = *(const uint32_t *)(simg + (size_t)gyc * W + gxc);
+    }
+    if (!interior) {
+        const uint32_t id0 = ch.op[0] ? 0u : 0xFFFFFFFFu;
+#pragma unroll
+        for (int j = 0; j < NR; j++) {
+            const int gy = Y0 + j;
+            const uint32_t m = (gy >= 0 && gy < H) ? cm : 0u;
+            R[j] = (R[j] & m) | (id0 & ~m);
+        }
+    }
+
+    int ycum = 0;
+    for (int o = 0; o < ch.n; o++) {
+        const int rx = ch.rx[o], ry = ch.ry[o];
+        const bool mx = ch.op[o] != 0;
+#define GOF_STREAM_OP(RR)                                  \
+    if (mx)                                                \
+        stream_op_bits<NR, true, RR>(R, rx);               \
+    else                                                   \
+        stream_op_bits<NR, false, RR>(R, rx);
+        switch (ry) {
+        case 0: GOF_STREAM_OP(0) break;
+        case 1: GOF_STREAM_OP(1) break;
+        case 2: GOF_STREAM_OP(2) break;
+        case 3: GOF_STREAM_OP(3) break;
+        default: GOF_STREAM_OP(4) break;
+        }
+#undef GOF_STREAM_OP
+        ycum += ry;
+        if (o + 1 < ch.n && !interior) {
+            const uint32_t idn = ch.op[o + 1] ? 0u : 0xFFFFFFFFu;
+#pragma unroll
+            for (int j = 0; j < NR; j++) {
+                const int gy = Y0 + ycum + j;
+                const uint32_t m = (gy >= 0 && gy < H) ? cm : 0u;
+                R[j] = (R[j] & m) | (idn & ~m);
+            }
+        }
+    }
+
+    if (lane >= HQ && lane < 64 - HQ && gx0 < W) {
+#pragma unroll
+        for (int j = 0; j < NR; j++) {
+            const int gy = y0 + j;
+            if (j < rows_out && gy < H)
+                *(uint32_t *)(dimg + (size_t)gy * W + gx0) = R[j];
+        }
+    }
+}
+
+template <int NR>
+__global__ __launch_bounds__(64) void morph_stream_kernel(const uint8_t *__restrict__ src,
+                                                           uint8_t *__restrict__ dst, int H, int W,
+                                                           RectChain ch, int HQ, int RY, int fast)
+{
+    // one wave per workgroup: the waves are independent, and single-wave
+    // workgroups let the dispatcher balance the (few thousand) strips over the SIMDs
+    const int lane = threadIdx.x;
+    const int rows_out = NR - 2 * RY;
+    const int strip_px = (64 - 2 * HQ) * 4;
+    const int sx0 = blockIdx.x * strip_px;   // first output px of this wave's strip
+    const int y0 = blockIdx.y * rows_out;
+    if (sx0 >= W || y0 >= H)
+        return;   // whole wave; there is no barrier in this kernel
+    const size_t N = (size_t)H * W;
+    const uint8_t *simg = src + (size_t)blockIdx.z * N;
+    uint8_t *dimg = dst + (size_t)blockIdx.z * N;
+    const int gx0 = sx0 - 4 * HQ + 4 * lane;   // image x of this lane's first px (multiple of 4)
+    const int Y0 = y0 - RY;
+
+    // in-image byte mask of this lane's column, as seen by the packed halves
+    uint32_t cm = 0;
+    if (gx0 >= 0 && gx0 < W)
+        cm = (W - gx0) >= 4 ? 0xFFFFFFFFu : ((1u << (8 * (W - gx0))) - 1u);
+    const uint32_t cmE = cm & 0x00FF00FFu, cmO = (cm >> 8) & 0x00FF00FFu;
+
+    uint32_t E[NR], O[NR];
+    const uint32_t id0 = ch.op[0] ? 0u : 0x00FF00FFu;
+    if (fast) {
+        // branch-free: clamped (always valid) addresses, so that all NR row loads
+        // are in flight together; out-of-image data is masked to the identity after
+        const int gxc = gx0 < 0 ? 0 : (gx0 > W - 4 ? W - 4 : gx0);
+        uint32_t raw[NR];
+#pragma unroll
+        for (int j = 0; j < NR; j++) {
+            const int gy = Y0 + j;
+            const int gyc = gy < 0 ? 0 : (gy > H - 1 ? H - 1 : gy);
+            raw[j] = *(const uint32_t *)(simg + (size_t)gyc * W + gxc);
+        }
+#pragma unroll
+        for (int j = 0; j < NR; j++) {
+            const int gy = Y0 + j;
+            const bool rowin = gy >= 0 && gy < H;
+            const uint32_t mE = rowin ? cmE : 0u, mO = rowin ? cmO : 0u;
+            E[j] = ((raw[j] & 0x00FF00FFu) & mE) | (id0 & ~mE);
+            O[j] = (((raw[j] >> 8) & 0x00FF00FFu) & mO) | (id0 & ~mO);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NR; j++) {
+            const int gy = Y0 + j;
+            uint32_t v = 0;
+            const bool rowin = gy >= 0 && gy < H;
+            if (rowin && cm) {
+                const uint8_t *p = simg + (size_t)gy * W + gx0;
+                const int nvalid = W - gx0 < 4 ? W - gx0 : 4;
+                for (int b = 0; b < nvalid; b++)
+                    v |= (uint32_t)p[b] << (8 * b);
+            }
+            const uint32_t mE = rowin ? cmE : 0u, mO = rowin ? cmO : 0u;
+            E[j] = ((v & 0x00FF00FFu) & mE) | (id0 & ~mE);
+            O[j] = (((v >> 8) & 0x00FF00FFu) & mO) | (id0 & ~mO);
+        }
+    }
+
+    int ycum = 0;
+    for (int o = 0; o < ch.n; o++) {
+        const int rx = ch.rx[o], ry = ch.ry[o];
+        const bool mx = ch.op[o] != 0;
+#define GOF_STREAM_OP(RR)                                         \
+    if (mx)                                                       \
+        stream_op<NR, true, RR>(E, O, rx);                        \
+    else                                                          \
+        stream_op<NR, false, RR>(E, O, rx);
+        switch (ry) {
+        case 0: GOF_STREAM_OP(0) break;
+        case 1: GOF_STREAM_OP(1) break;
+        case 2: GOF_STREAM_OP(2) break;
+        case 3: GOF_STREAM_OP(3) break;
+        default: GOF_STREAM_OP(4) break;
+        }
+#undef GOF_STREAM_OP
+        ycum += ry;
+        if (o + 1 < ch.n) {
+            // what cv2's constant border does to the intermediate image
+            const uint32_t idn = ch.op[o + 1] ? 0u : 0x00FF00FFu;
+#pragma unroll
+            for (int j = 0; j < NR; j++) {
+                const int gy = Y0 + ycum + j;
+                const bool rowin = gy >= 0 && gy < H;
+                const uint32_t mE = rowin ? cmE : 0u, mO = rowin ? cmO : 0u;
+                E[j] = (E[j] & mE) | (idn & ~mE);
+                O[j] = (O[j] & mO) | (idn & ~mO);
+            }
+        }
+    }
+
+    if (lane >= HQ && lane < 64 - HQ && gx0 < W) {
+#pragma unroll
+        for (int j = 0; j < NR; j++) {
+            const int gy = y0 + j;
+            if (j < rows_out && gy < H) {
+                const uint32_t v = E[j] | (O[j] << 8);
+                uint8_t *p = dimg + (size_t)gy * W + gx0;
+                if (fast) {
+                    *(uint32_t *)p = v;
+                } else {
+                    const int nvalid = W - gx0 < 4 ? W - gx0 : 4;
+                    for (int b = 0; b < nvalid; b++)
+                        p[b] = (uint8_t)(v >> (8 * b));
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // step 0 (optional): cv.cvtColor(X, COLOR_BGR2GRAY | COLOR_RGB2GRAY), pipeline.py:458-459
 // 8-bit fixed point of the OpenCV 3.4 line the reference pins [OPENCV-RECALL]:
 //   Y = (B*1868 + G*9617 + R*4899 + 2^13) >> 14
@@ -759,8 +1147,8 @@ hipError_t mog2_apply(const uint8_t *frame, uint8_t *mask, const Mog2State &st, 
                       int w, int c, const Mog2Consts &k, bool fused_blur3, const Taps &t,
                       hipStream_t s)
 {
-    if (n_img < 1 || h < 1 || w < 1 || (h + TH - 1) / TH > 65535 || n_img > 65535 ||
-        st.np < (size_t)n_img * h * w || k.nmix < 1 || k.nmix > kMaxModes)
+    if (n_img < 1 || h < 1 || w < 1 || n_img > 65535 || st.np < (size_t)n_img * h * w ||
+        k.nmix < 1 || k.nmix > kMaxModes)
         return hipErrorInvalidValue;
     if (fused_blur3 && (t.nkx != 3 || t.nky != 3))
         return hipErrorInvalidValue;
@@ -769,10 +1157,18 @@ hipError_t mog2_apply(const uint8_t *frame, uint8_t *mask, const Mog2State &st, 
         kx = t.kx[0] | (t.kx[1] << 10) | (t.kx[2] << 20);
         ky = t.ky[0] | (t.ky[1] << 10) | (t.ky[2] << 20);
     }
-    dim3 g = grid3(w, h, n_img, TW, TH);
+    // 1-D tile index per image, padded to a multiple of 8 for the XCD swizzle
+    const long ntiles = (long)((w + TW - 1) / TW) * ((h + TH - 1) / TH);
+    if (ntiles > 0x7ffffff0L)
+        return hipErrorInvalidValue;
+    // both knobs are re-read per launch so that a bench can flip them after its warm-up
+    const int swz = (getenv("GOF_XCD_SWIZZLE") ? atoi(getenv("GOF_XCD_SWIZZLE")) & 255 : 0) |
+                    (getenv("GOF_ABLATE") ? atoi(getenv("GOF_ABLATE")) << 8 : 0);
+    const long span = (swz & 255) > 1 ? 8L * (swz & 255) : 8;
+    dim3 g((unsigned)(((ntiles + span - 1) / span) * span), (unsigned)n_img, 1);
 #define GOF_LAUNCH_MOG2(CC, BB)                                                              \
     hipLaunchKernelGGL((mog2_kernel<CC, BB>), g, dim3(256), 0, s, frame, mask, st.planes,    \
-                       st.modes, st.np, h, w, k, kx, ky)
+                       st.modes, st.np, h, w, k, kx, ky, swz)
     if (fused_blur3) {
         switch (c) {
         case 1: GOF_LAUNCH_MOG2(1, true); break;
@@ -851,16 +1247,68 @@ bool morph_rect_chain_supported(const RectChain &ch)
     return chain_geometry(ch, &HQ, &RY, &lds);
 }
 
+namespace {
+// the register-streaming kernel takes chains of small rectangular ops
+bool stream_geometry(const RectChain &ch, int *HQ, int *RY)
+{
+    if (ch.n < 1 || ch.n > 8)
+        return false;
+    int hq = 0, ry = 0;
+    for (int i = 0; i < ch.n; i++) {
+        if (ch.rx[i] < 0 || ch.rx[i] > 4 || ch.ry[i] < 0 || ch.ry[i] > 4 ||
+            (ch.op[i] != 0 && ch.op[i] != 1))
+            return false;
+        hq += ch.rx[i] > 0 ? 1 : 0;
+        ry += ch.ry[i];
+    }
+    *HQ = hq;
+    *RY = ry;
+    return ry <= 16 && hq <= 8;
+}
+}  // namespace
+
 hipError_t morph_rect_chain(const uint8_t *src, uint8_t *dst, int n_img, int h, int w,
-                            const RectChain &ch, hipStream_t s)
+                            const RectChain &ch, bool chain_valued, hipStream_t s)
 {
     int HQ, RY;
     size_t lds;
-    if (n_img < 1 || h < 1 || w < 1 || !chain_geometry(ch, &HQ, &RY, &lds) ||
-        (h + CTH - 1) / CTH > 65535 || n_img > 65535)
+    if (n_img < 1 || h < 1 || w < 1 || n_img > 65535)
         return hipErrorInvalidValue;
     // dword loads/stores need every row (and every image) to start 4-byte aligned
     const int fast = (w % 4 == 0) && ((uintptr_t)src % 4 == 0) && ((uintptr_t)dst % 4 == 0);
+    static const bool no_stream = getenv("GOF_MORPH_LDS") != nullptr;   // A/B knob
+    if (!no_stream && stream_geometry(ch, &HQ, &RY)) {
+        int NR = RY <= 4 ? 24 : (RY <= 8 ? 32 : 48);
+        if (const char *e = getenv("GOF_MORPH_NR"))   // tuning knob
+            if (atoi(e) - 2 * RY >= 4)
+                NR = atoi(e);
+        const int rows_out = NR - 2 * RY, strip_px = (64 - 2 * HQ) * 4;
+        if ((h + rows_out - 1) / rows_out > 65535)
+            return hipErrorInvalidValue;
+        dim3 g((unsigned)((w + strip_px - 1) / strip_px), (unsigned)((h + rows_out - 1) / rows_out),
+               (unsigned)n_img);
+        static const bool no_bits = getenv("GOF_MORPH_NOBITS") != nullptr;   // A/B knob
+        if (chain_valued && fast && !no_bits) {
+            switch (NR) {
+            case 16: hipLaunchKernelGGL(morph_stream_bits_kernel<16>, g, dim3(64), 0, s, src, dst, h, w, ch, HQ, RY); break;
+            case 24: hipLaunchKernelGGL(morph_stream_bits_kernel<24>, g, dim3(64), 0, s, src, dst, h, w, ch, HQ, RY); break;
+            case 32: hipLaunchKernelGGL(morph_stream_bits_kernel<32>, g, dim3(64), 0, s, src, dst, h, w, ch, HQ, RY); break;
+            case 48: hipLaunchKernelGGL(morph_stream_bits_kernel<48>, g, dim3(64), 0, s, src, dst, h, w, ch, HQ, RY); break;
+            default: return hipErrorInvalidValue;
+            }
+            return hipGetLastError();
+        }
+        switch (NR) {
+        case 16: hipLaunchKernelGGL(morph_stream_kernel<16>, g, dim3(64), 0, s, src, dst, h, w, ch, HQ, RY, fast); break;
+        case 24: hipLaunchKernelGGL(morph_stream_kernel<24>, g, dim3(64), 0, s, src, dst, h, w, ch, HQ, RY, fast); break;
+        case 32: hipLaunchKernelGGL(morph_stream_kernel<32>, g, dim3(64), 0, s, src, dst, h, w, ch, HQ, RY, fast); break;
+        case 48: hipLaunchKernelGGL(morph_stream_kernel<48>, g, dim3(64), 0, s, src, dst, h, w, ch, HQ, RY, fast); break;
+        default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
+    if (!chain_geometry(ch, &HQ, &RY, &lds) || (h + CTH - 1) / CTH > 65535)
+        return hipErrorInvalidValue;
     hipLaunchKernelGGL(morph_chain_kernel, grid3(w, h, n_img, 4 * CTWD, CTH), dim3(256), lds, s,
                        src, dst, h, w, ch, HQ, RY, fast);
     return hipGetLastError();
