@@ -166,16 +166,25 @@ void gof_pipeline_destroy(gof_pipeline *p);
 /* frames: streams x (h, w, c); masks: streams x (h, w) */
 int gof_pipeline_apply_host(gof_pipeline *p, const uint8_t *frames, uint8_t *masks);
 int gof_pipeline_apply_dev(gof_pipeline *p, const void *d_frames, void *d_masks, void *stream);
+/* n_frames consecutive frames of every stream in one call (temporal blocking:
+ * the MOG2 model is read and written once per 8 frames instead of once per
+ * frame; the masks are identical to n_frames single-frame calls).
+ * frames: n_frames x streams x (h, w, c); masks: n_frames x streams x (h, w). */
+int gof_pipeline_apply_host_many(gof_pipeline *p, const uint8_t *frames, uint8_t *masks,
+                                 int n_frames);
+int gof_pipeline_apply_dev_many(gof_pipeline *p, const void *d_frames, void *d_masks, int n_frames,
+                                void *stream);
 gof_mog2 *gof_pipeline_mog2(gof_pipeline *p);   /* NULL for an FD pipeline */
 /* mean number of Gaussian modes in use per pixel (m-bar of the byte model) */
 int gof_pipeline_mean_modes(gof_pipeline *p, double *mean_modes);
-/* Algorithmic HBM bytes of one apply(), given m-bar:
+/* Algorithmic HBM bytes of one apply of n_frames frames, given m-bar:
  *   *detector_bytes: the dominant kernel alone (fused blur + MOG2), per pixel
- *       c + 1 + 2*(1 + 4*(2+c)*mbar)    = 6 + 40*mbar for BGR
- *   *total_bytes: every kernel of the step (adds 2 B/px per morphology kernel
- *       and 2*c B/px for a blur that is not fused). */
-int gof_pipeline_algorithmic_bytes(gof_pipeline *p, double mean_modes, double *total_bytes,
-                                   double *detector_bytes);
+ *       n_frames*(c + 1) + ceil(n_frames/8) * 2*(1 + 4*(2+c)*mbar)
+ *       = 6 + 40*mbar for one BGR frame
+ *   *total_bytes: every kernel of the step (adds 2 B/px/frame per morphology
+ *       kernel and 2*c B/px/frame for a blur that is not fused). */
+int gof_pipeline_algorithmic_bytes(gof_pipeline *p, double mean_modes, int n_frames,
+                                   double *total_bytes, double *detector_bytes);
 
 /* ---- step 4 helper, host only (NOT part of the GPU hot path) -------------
  * cv.findContours(mask, RETR_EXTERNAL, CHAIN_APPROX_NONE) as the reference's

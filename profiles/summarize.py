@@ -56,7 +56,7 @@ def main(d):
             # reports 1/2 of the bytes of a wide coalesced streaming read -> x2.
             fetch_raw = cs["FETCH_SIZE"] * 1024.0
             write = cs["WRITE_SIZE"] * 1024.0
-            rec = {"config": {"streams": 8, "height": 1080, "width": 1920},   # bench.py defaults
+            rec = {"config": {"streams": 8, "height": 1080, "width": 1920, "frames_per_step": 1},   # bench.py defaults
                    "kernel": k, "fetch_size_raw_bytes": fetch_raw, "fetch_bytes_corrected": 2 * fetch_raw,
                    "write_bytes": write, "hbm_bytes_per_launch": 2 * fetch_raw + write,
                    "note": "per launch, mean of the last half of the dispatches; FETCH_SIZE x2 per "

@@ -97,8 +97,11 @@ SIGNATURES = {
     "gof_pipeline_apply_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gof_pipeline_mog2": (C.c_void_p, [C.c_void_p]),
     "gof_pipeline_mean_modes": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
-    "gof_pipeline_algorithmic_bytes": (C.c_int, [C.c_void_p, C.c_double, C.POINTER(C.c_double),
-                                                 C.POINTER(C.c_double)]),
+    "gof_pipeline_apply_host_many": (C.c_int, [C.c_void_p, _u8p, _u8p, C.c_int]),
+    "gof_pipeline_apply_dev_many": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                              C.c_void_p]),
+    "gof_pipeline_algorithmic_bytes": (C.c_int, [C.c_void_p, C.c_double, C.c_int,
+                                                 C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "gof_find_external_contours": (C.c_int, [_u8p, C.c_int, C.c_int,
                                              C.POINTER(C.POINTER(C.c_int32)),
                                              C.POINTER(C.POINTER(C.c_int32)),

@@ -176,18 +176,27 @@ int check_geom(int n, int h, int w, int c)
 
 hipStream_t pick(gof_ctx *ctx, void *stream) { return stream ? (hipStream_t)stream : ctx->stream; }
 
-// cv2 BackgroundSubtractorMOG2Impl::apply, learningRate = -1 [OPENCV-RECALL]:
+// Constants of the next T (<= kMaxT) frames; advances the frame counter by T.
+// cv2 BackgroundSubtractorMOG2Impl::apply with learningRate = -1 [OPENCV-RECALL]:
 //   ++nframes; lr = 1/min(2*nframes, history) in double;
 //   alphaT = float(lr); prune = float(-lr * fCT)
-gofk::Mog2Consts next_consts(gof_mog2 *m)
+gofk::Mog2Consts next_consts(gof_mog2 *m, int T)
 {
-    ++m->nframes;
-    int d = 2 * m->nframes < m->p.history ? 2 * m->nframes : m->p.history;
-    double lr = 1.0 / (double)d;
     gofk::Mog2Consts k;
-    k.alphaT = (float)lr;
+    for (int i = 0; i < gofk::kMaxT; i++) {
+        k.alphaT_f[i] = 0.f;
+        k.prune_f[i] = 0.f;
+    }
+    for (int i = 0; i < T; i++) {
+        ++m->nframes;
+        const int d = 2 * m->nframes < m->p.history ? 2 * m->nframes : m->p.history;
+        const double lr = 1.0 / (double)d;
+        k.alphaT_f[i] = (float)lr;
+        k.prune_f[i] = (float)(-lr * m->p.ct);
+    }
+    k.alphaT = k.alphaT_f[0];
     k.alpha1 = 1.f - k.alphaT;
-    k.prune = (float)(-lr * m->p.ct);
+    k.prune = k.prune_f[0];
     k.Tb = m->p.var_threshold;
     k.TB = m->p.background_ratio;
     k.Tg = m->p.var_threshold_gen;
@@ -503,10 +512,10 @@ int gof_mog2_apply_dev(gof_mog2 *m, const void *d_frames, void *d_masks, void *s
     if (!m || !d_frames || !d_masks)
         return fail(GOF_EINVAL, "NULL argument");
     GOF_HIP(hipSetDevice(m->ctx->device));
-    gofk::Mog2Consts k = next_consts(m);
+    gofk::Mog2Consts k = next_consts(m, 1);
     gofk::Taps none{};
     hipError_t e = gofk::mog2_apply((const uint8_t *)d_frames, (uint8_t *)d_masks, m->view(),
-                                    m->streams, m->h, m->w, m->c, k, false, none,
+                                    m->streams, m->h, m->w, m->c, 1, k, false, none,
                                     pick(m->ctx, stream));
     if (e != hipSuccess) {
         --m->nframes;
@@ -847,22 +856,28 @@ void gof_pipeline_destroy(gof_pipeline *p)
 
 gof_mog2 *gof_pipeline_mog2(gof_pipeline *p) { return p ? p->mog2 : nullptr; }
 
-int gof_pipeline_apply_dev(gof_pipeline *p, const void *d_frames, void *d_masks, void *stream)
+int gof_pipeline_apply_dev_many(gof_pipeline *p, const void *d_frames, void *d_masks, int n_frames,
+                                void *stream)
 {
     if (!p || !d_frames || !d_masks)
         return fail(GOF_EINVAL, "NULL argument");
+    if (n_frames < 1 || n_frames > 4096)
+        return fail(GOF_EINVAL, "n_frames must be in [1, 4096], got %d", n_frames);
     GOF_HIP(hipSetDevice(p->ctx->device));
     hipStream_t s = pick(p->ctx, stream);
     const gof_pipeline_desc &d = p->d;
-    const size_t npx = (size_t)d.streams * d.h * d.w;
+    const int T = n_frames;
+    const size_t npx = (size_t)d.streams * d.h * d.w;   // pixels of ONE frame of every stream
+    if ((size_t)T * d.streams > 65535)
+        return fail(GOF_EINVAL, "n_frames * streams must not exceed 65535");
     int rc;
 
     // step 1 (pipeline.py:462-467) -- unless it is fused into step 2
     const uint8_t *x = (const uint8_t *)d_frames;
     if (d.blur == GOF_BLUR_GAUSS && !p->fuse_blur3) {
-        if ((rc = p->blurred.reserve(npx * d.c)))
+        if ((rc = p->blurred.reserve((size_t)T * npx * d.c)))
             return rc;
-        GOF_HIP(gofk::blur_sep_q8(x, (uint8_t *)p->blurred.p, d.streams, d.h, d.w, d.c, p->taps, s));
+        GOF_HIP(gofk::blur_sep_q8(x, (uint8_t *)p->blurred.p, T * d.streams, d.h, d.w, d.c, p->taps, s));
         x = (const uint8_t *)p->blurred.p;
     }
 
@@ -874,41 +889,46 @@ int gof_pipeline_apply_dev(gof_pipeline *p, const void *d_frames, void *d_masks,
     // step 2 (pipeline.py:470)
     uint8_t *det_out = (uint8_t *)d_masks;
     if (d.n_morph > 0) {
-        if ((rc = p->m0.reserve(npx)))
+        if ((rc = p->m0.reserve((size_t)T * npx)))
             return rc;
         det_out = (uint8_t *)p->m0.p;
     }
     if (p->mog2) {
-        gofk::Mog2Consts k = next_consts(p->mog2);
-        hipError_t e = gofk::mog2_apply(x, det_out, p->mog2->view(), d.streams, d.h, d.w, d.c, k,
-                                        p->fuse_blur3, p->taps, s);
-        if (e != hipSuccess) {
-            --p->mog2->nframes;
-            return fail(GOF_EHIP, "mog2 launch: %s", hipGetErrorString(e));
+        // temporal blocking: up to kMaxT frames per launch, the model moves once
+        for (int t0 = 0; t0 < T; t0 += gofk::kMaxT) {
+            const int tn = T - t0 < gofk::kMaxT ? T - t0 : gofk::kMaxT;
+            gofk::Mog2Consts k = next_consts(p->mog2, tn);
+            hipError_t e = gofk::mog2_apply(x + (size_t)t0 * npx * d.c, det_out + (size_t)t0 * npx,
+                                            p->mog2->view(), d.streams, d.h, d.w, d.c, tn, k,
+                                            p->fuse_blur3, p->taps, s);
+            if (e != hipSuccess) {
+                p->mog2->nframes -= tn;
+                return fail(GOF_EHIP, "mog2 launch: %s", hipGetErrorString(e));
+            }
         }
     } else {
-        if ((rc = gof_fd_apply_dev(p->fd, x, det_out, s)))
-            return rc;
+        for (int t = 0; t < T; t++)
+            if ((rc = gof_fd_apply_dev(p->fd, x + (size_t)t * npx * d.c, det_out + (size_t)t * npx, s)))
+                return rc;
     }
-
     if (prof)
         GOF_HIP(hipEventRecord(ev[1], s));
 
-    // step 3 (pipeline.py:473-475)
+    // step 3 (pipeline.py:473-475): all T * streams masks in one launch per kernel
     if (d.n_morph > 0) {
         if (p->chain_ok) {
             // detector masks are chain-valued ({0, shadow, 255} / {0, 84, 85} / {0, 255})
-            GOF_HIP(gofk::morph_rect_chain(det_out, (uint8_t *)d_masks, d.streams, d.h, d.w,
+            GOF_HIP(gofk::morph_rect_chain(det_out, (uint8_t *)d_masks, T * d.streams, d.h, d.w,
                                            p->chain, true, s));
         } else {
-            if (d.n_morph > 1 && (rc = p->m1.reserve(npx)))
+            if (d.n_morph > 1 && (rc = p->m1.reserve((size_t)T * npx)))
                 return rc;
             const uint8_t *src = det_out;
             for (int i = 0; i < d.n_morph; i++) {
                 uint8_t *dst = i == d.n_morph - 1 ? (uint8_t *)d_masks
                                : (src == (const uint8_t *)p->m0.p ? (uint8_t *)p->m1.p
                                                                    : (uint8_t *)p->m0.p);
-                GOF_HIP(gofk::morph_generic(d.morph[i].op, src, dst, d.streams, d.h, d.w,
+                GOF_HIP(gofk::morph_generic(d.morph[i].op, src, dst, T * d.streams, d.h, d.w,
                                             p->sebits[(size_t)i], s));
                 src = dst;
             }
@@ -921,22 +941,35 @@ int gof_pipeline_apply_dev(gof_pipeline *p, const void *d_frames, void *d_masks,
     return GOF_OK;
 }
 
-int gof_pipeline_apply_host(gof_pipeline *p, const uint8_t *frames, uint8_t *masks)
+int gof_pipeline_apply_dev(gof_pipeline *p, const void *d_frames, void *d_masks, void *stream)
+{
+    return gof_pipeline_apply_dev_many(p, d_frames, d_masks, 1, stream);
+}
+
+int gof_pipeline_apply_host_many(gof_pipeline *p, const uint8_t *frames, uint8_t *masks,
+                                 int n_frames)
 {
     if (!p || !frames || !masks)
         return fail(GOF_EINVAL, "NULL argument");
+    if (n_frames < 1 || n_frames > 4096)
+        return fail(GOF_EINVAL, "n_frames must be in [1, 4096], got %d", n_frames);
     GOF_HIP(hipSetDevice(p->ctx->device));
     hipStream_t s = p->ctx->stream;
-    const size_t npx = (size_t)p->d.streams * p->d.h * p->d.w;
+    const size_t npx = (size_t)n_frames * p->d.streams * p->d.h * p->d.w;
     int rc;
     if ((rc = p->in.reserve(npx * p->d.c)) || (rc = p->out.reserve(npx)))
         return rc;
     GOF_HIP(hipMemcpyAsync(p->in.p, frames, npx * p->d.c, hipMemcpyHostToDevice, s));
-    if ((rc = gof_pipeline_apply_dev(p, p->in.p, p->out.p, nullptr)))
+    if ((rc = gof_pipeline_apply_dev_many(p, p->in.p, p->out.p, n_frames, nullptr)))
         return rc;
     GOF_HIP(hipMemcpyAsync(masks, p->out.p, npx, hipMemcpyDeviceToHost, s));
     GOF_HIP(hipStreamSynchronize(s));
     return GOF_OK;
+}
+
+int gof_pipeline_apply_host(gof_pipeline *p, const uint8_t *frames, uint8_t *masks)
+{
+    return gof_pipeline_apply_host_many(p, frames, masks, 1);
 }
 
 int gof_pipeline_profile_enable(gof_pipeline *p, int enable, int capacity)
@@ -995,24 +1028,28 @@ int gof_pipeline_mean_modes(gof_pipeline *p, double *mean_modes)
     return GOF_OK;
 }
 
-int gof_pipeline_algorithmic_bytes(gof_pipeline *p, double mean_modes, double *total_bytes,
-                                   double *detector_bytes)
+int gof_pipeline_algorithmic_bytes(gof_pipeline *p, double mean_modes, int n_frames,
+                                   double *total_bytes, double *detector_bytes)
 {
-    if (!p || !total_bytes || !detector_bytes)
-        return fail(GOF_EINVAL, "NULL argument");
+    if (!p || !total_bytes || !detector_bytes || n_frames < 1)
+        return fail(GOF_EINVAL, "bad argument");
     const gof_pipeline_desc &d = p->d;
     const double npx = (double)d.streams * d.h * d.w;
-    // detector kernel: frame in, mask out, and its state
-    double det = d.c + 1.0;
-    if (p->mog2)
-        det += 2.0 * (1.0 + 4.0 * (2 + d.c) * mean_modes);   // model read + write
-    else
-        det += 2.0 * d.c;                                      // X_{t-1} read, X_t kept
+    const double T = n_frames;
+    // detector: every frame in and every mask out; the MOG2 model moves once per
+    // launch of up to kMaxT frames (temporal blocking), FD state once per frame
+    double det = T * (d.c + 1.0);
+    if (p->mog2) {
+        const double launches = (double)((n_frames + gofk::kMaxT - 1) / gofk::kMaxT);
+        det += launches * 2.0 * (1.0 + 4.0 * (2 + d.c) * mean_modes);   // model read + write
+    } else {
+        det += T * 2.0 * d.c;                                  // X_{t-1} read, X_t kept
+    }
     double tot = det;
     if (d.blur == GOF_BLUR_GAUSS && !p->fuse_blur3)
-        tot += 2.0 * d.c;                                      // blurred image written + read
+        tot += T * 2.0 * d.c;                                  // blurred image written + read
     const int morph_kernels = d.n_morph == 0 ? 0 : (p->chain_ok ? 1 : d.n_morph);
-    tot += 2.0 * morph_kernels;                                // each reads a mask, writes a mask
+    tot += T * 2.0 * morph_kernels;                            // each reads a mask, writes a mask
     *total_bytes = npx * tot;
     *detector_bytes = npx * det;
     return GOF_OK;

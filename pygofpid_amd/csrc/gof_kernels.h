@@ -13,13 +13,21 @@ constexpr int kMaxKsize = 31;
 // Per-frame MOG2 scalars (cv2 BackgroundSubtractorMOG2Impl::apply computes the
 // rates on the host once per frame; restated in gof_api.cpp).
 struct Mog2Consts {
-    float alphaT, alpha1, prune;
+    // learning rates of the (up to kMaxT) frames of one launch, computed on the
+    // host exactly as cv2 does [BackgroundSubtractorMOG2Impl::apply]:
+    //   lr = 1.0 / min(2 n, history) in double; alphaT = float(lr);
+    //   prune = float(-lr * ct);  (alpha1 = 1.f - alphaT is formed in the kernel)
+    float alphaT_f[8], prune_f[8];
+    float alphaT, alpha1, prune;   // scratch: the current frame's values
     float Tb, TB, Tg;
     float var_init, var_min, var_max, tau;
     int nmix;
     int detect_shadows;
     int shadow_value;
 };
+
+// most frames one launch steps through (temporal blocking)
+constexpr int kMaxT = 8;
 
 // Structure-of-arrays model in HBM, np = plane pitch in floats (>= streams*h*w):
 //   plane(m, f) = state + (m*(2+C) + f) * np ; f = 0 weight, 1 variance, 2+ch mean[ch]
@@ -50,11 +58,13 @@ struct RectChain {         // fused chain of rectangular erode/dilate ops
 hipError_t blur_sep_q8(const uint8_t *src, uint8_t *dst, int n_img, int h, int w, int c,
                        const Taps &t, hipStream_t s);
 
-// mask[n_img][h][w] <- MOG2 update of state with frame[n_img][h][w][c].
-// fused_blur3: the frame is first blurred with the 3x3 taps t (REFLECT_101)
+// mask[T][n_img][h][w] <- T successive MOG2 updates of state with
+// frame[T][n_img][h][w][c] (the model is loaded and stored once per launch);
+// frame ti uses k.alphaT_f[ti] / k.prune_f[ti].
+// fused_blur3: each frame is first blurred with the 3x3 taps t (REFLECT_101)
 // inside the same kernel (LDS-staged tile), no intermediate image.
 hipError_t mog2_apply(const uint8_t *frame, uint8_t *mask, const Mog2State &st, int n_img, int h,
-                      int w, int c, const Mog2Consts &k, bool fused_blur3, const Taps &t,
+                      int w, int c, int T, const Mog2Consts &k, bool fused_blur3, const Taps &t,
                       hipStream_t s);
 
 hipError_t fd_apply(const uint8_t *cur, const uint8_t *prev, bool has_prev, int ithr,

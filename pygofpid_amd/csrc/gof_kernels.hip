@@ -28,8 +28,6 @@ __device__ __forceinline__ int reflect101(int p, int len)
     return p < len ? p : period - p;
 }
 
-__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
-
 // ---------------------------------------------------------------------------
 // MOG2 (+ optional fused 3x3 fixed-point blur)
 // ---------------------------------------------------------------------------
@@ -226,6 +224,19 @@ __device__ __forceinline__ uint8_t mog2_update(PixelModel<C> &M, int &nmodes_io,
     return shadow ? (uint8_t)k.shadow_value : (uint8_t)255;
 }
 
+typedef unsigned short gof_u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_mul_u16(uint32_t a, uint32_t b)
+{
+    gof_u16x2 r = __builtin_bit_cast(gof_u16x2, a) * __builtin_bit_cast(gof_u16x2, b);
+    return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ uint32_t pk_mad_u16(uint32_t a, uint32_t b, uint32_t c)
+{
+    gof_u16x2 r = __builtin_bit_cast(gof_u16x2, a) * __builtin_bit_cast(gof_u16x2, b) +
+                  __builtin_bit_cast(gof_u16x2, c);
+    return __builtin_bit_cast(uint32_t, r);
+}
+
 // REFLECT_101 for a reach of one pixel: -1 -> 1, len -> len-2 (len == 1 -> 0)
 __device__ __forceinline__ int reflect1(int p, int len)
 {
@@ -236,66 +247,85 @@ __device__ __forceinline__ int reflect1(int p, int len)
     return p;
 }
 
-template <int C, bool BLUR3>
+// Temporal blocking.  MOG2 is a per-pixel recurrence over time; nothing couples
+// neighbouring pixels except the blur of the INPUT frame.  One launch therefore
+// takes T consecutive frames of every stream: the pixel's model is loaded once,
+// updated T times in registers (one mask byte written per frame) and stored
+// once, which divides the dominant HBM traffic (the model, ~49 of 55 B/px) by T.
+// T = 1 is the per-frame form GOFPID.detect() needs.  Results are identical to T
+// single-frame launches: same statements in the same order on the same values.
+// MULTI = false is the single-frame instance (T == 1 known at compile time: no
+// loop-carried state, 64 VGPRs, 8 waves per SIMD).
+template <int C, bool BLUR3, bool MULTI>
 __global__ __launch_bounds__(256) void mog2_kernel(const uint8_t *__restrict__ frame,
                                                    uint8_t *__restrict__ mask,
                                                    float *__restrict__ planes,
                                                    uint8_t *__restrict__ modes, size_t np, int H,
-                                                   int W, Mog2Consts k, uint32_t kx012,
-                                                   uint32_t ky012, int xcd_swizzle)
+                                                   int W, int T_arg, size_t frame_stride,
+                                                   size_t mask_stride, Mog2Consts k, uint32_t kx012,
+                                                   uint32_t ky012)
 {
     constexpr int F = 2 + C;  // floats per mode
+    const int T = MULTI ? T_arg : 1;
     const int lane = threadIdx.x & 63;
     // wave-uniform values are forced into SGPRs: row index, row bases, plane bases
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    // XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs
-    // (b and b+8 share an L2).  Horizontally adjacent tiles share 128-B lines of
-    // the byte planes and of the frame rows, vertically adjacent ones share halo
-    // rows; giving each XCD one contiguous run of tiles keeps those lines in ONE
-    // L2 instead of fetching them from HBM once per XCD.  Speed only: any
-    // placement computes the same result.
-    const int tiles_x = (W + TW - 1) / TW;
-    const int ntiles = tiles_x * ((H + TH - 1) / TH);
-    // q = xcd_swizzle tiles in a row go to the SAME XCD (blocks b and b+8 share one);
-    // the 8 XCDs together still sweep 8q consecutive tiles, which keeps the DRAM
-    // pages they touch close together.
-    const int dbg = xcd_swizzle >> 8;   // profiles/ ablations only (GOF_ABLATE), 0 in production
-    xcd_swizzle &= 255;
-    int tidx = (int)blockIdx.x;
-    if (xcd_swizzle > 1) {
-        const int span = 8 * xcd_swizzle;
-        const int g = tidx / span, r = tidx - g * span;
-        tidx = g * span + (r & 7) * xcd_swizzle + (r >> 3);
-    }
-    if (tidx >= ntiles)
-        return;  // padding of the 1-D grid; whole workgroup, before any barrier
-    const int ty = tidx / tiles_x;
-    const int x0 = (tidx - ty * tiles_x) * TW, y0 = ty * TH;
-    const int img = blockIdx.y;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    const int img = blockIdx.z;
     const int x = x0 + lane, y = y0 + wave;
     const size_t N = (size_t)H * W;
-    const uint8_t *fimg = frame + (size_t)img * N * C;
 
-    // ---- stage the (TH+2) x (TW+2) px input tile: raw bytes, aligned dword
-    //      loads, each wave stages rows {wave, wave+4}; borders are resolved
-    //      when the tile is read ----
-    // dwords per staged row: misalignment slack + one dword of read-ahead for px()
-    constexpr int ROWD = ((TW + 2) * C + 3 + 3) / 4 + 1;
-    __shared__ uint32_t tile[BLUR3 ? (TH + 2) * ROWD : 1];
+    // raw (TH+2) x (TW+2) px input tiles of ALL frames of the launch (<= 10 KB):
+    // every global load of the kernel is issued up front, one barrier, and the
+    // frame loop below touches only LDS and registers
+    constexpr int ROWD = ((TW + 2) * C + 3 + 3) / 4 + 1;   // + misalignment slack + read-ahead of px()
+    constexpr int TILE = (TH + 2) * ROWD;
+    constexpr int NT = MULTI ? kMaxT : 1;
+    __shared__ uint32_t tiles[BLUR3 ? NT * TILE : 1];
     const int sx0 = x0 > 0 ? x0 - 1 : 0;
+    const int sx1 = (x0 + TW + 1) < W ? (x0 + TW + 1) : W;
+    const int nb = (sx1 - sx0) * C;
+
     if (BLUR3) {
-        const int sx1 = (x0 + TW + 1) < W ? (x0 + TW + 1) : W;
-        const int nb = (sx1 - sx0) * C;
+        // each wave stages rows {wave, wave+4} of every frame: raw bytes, aligned
+        // dword loads; borders are resolved when the tile is read
+        constexpr int NDW = (ROWD + 63) / 64;
+        uint32_t raw[NT][2][NDW];
 #pragma unroll
-        for (int rr = 0; rr < 2; rr++) {
-            const int r = wave + 4 * rr;
-            if (r < TH + 2) {
-                const int gy = clampi(reflect1(y0 - 1 + r, H), 0, H - 1);
-                const uint8_t *a = fimg + ((size_t)gy * W + sx0) * C;
-                const int mis = (int)((uintptr_t)a & 3);
-                const int ndw = (mis + nb + 3) >> 2;
-                for (int d = lane; d < ndw; d += 64)
-                    tile[r * ROWD + d] = ((const uint32_t *)(a - mis))[d];
+        for (int ti = 0; ti < NT; ti++) {
+            if (ti < T) {
+                const uint8_t *fimg = frame + (size_t)ti * frame_stride + (size_t)img * N * C;
+#pragma unroll
+                for (int rr = 0; rr < 2; rr++) {
+                    const int r = wave + 4 * rr;
+                    const int gy = reflect1(y0 - 1 + (r < TH + 2 ? r : 0), H);
+                    const int gyc = gy < H ? gy : H - 1;   // rows below a ragged last tile
+                    const uint8_t *a = fimg + ((size_t)gyc * W + sx0) * C;
+                    const int mis = (int)((uintptr_t)a & 3);
+                    const int ndw = (mis + nb + 3) >> 2;
+#pragma unroll
+                    for (int q = 0; q < NDW; q++) {
+                        const int d = lane + 64 * q;
+                        raw[ti][rr][q] = d < ndw ? ((const uint32_t *)(a - mis))[d] : 0u;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int ti = 0; ti < NT; ti++) {
+            if (ti < T) {
+#pragma unroll
+                for (int rr = 0; rr < 2; rr++) {
+                    const int r = wave + 4 * rr;
+                    if (r < TH + 2) {
+#pragma unroll
+                        for (int q = 0; q < NDW; q++) {
+                            const int d = lane + 64 * q;
+                            if (d < ROWD)
+                                tiles[ti * TILE + r * ROWD + d] = raw[ti][rr][q];
+                        }
+                    }
+                }
             }
         }
     }
@@ -309,88 +339,14 @@ __global__ __launch_bounds__(256) void mog2_kernel(const uint8_t *__restrict__ f
     const size_t rowoff = (size_t)img * N + (size_t)yy * W; // wave-uniform
     float *const prow = planes + rowoff;
     PixelModel<C> M;
-    int nmodes = modes[rowoff + xl];
+    int nmodes = valid ? (int)modes[rowoff + xl] : 0;
     M.w[0] = prow[xl];
     M.var[0] = (prow + np)[xl];
 #pragma unroll
     for (int c = 0; c < C; c++)
         M.mu[0][c] = (prow + (size_t)(2 + c) * np)[xl];
-
-    float xin[C];
-    if (BLUR3) {
-        __syncthreads();
-        const int kx0 = (int)(kx012 & 1023), kx1 = (int)((kx012 >> 10) & 1023), kx2 = (int)(kx012 >> 20);
-        const int ky[3] = {(int)(ky012 & 1023), (int)((ky012 >> 10) & 1023), (int)(ky012 >> 20)};
-        // byte offsets (within a staged row) of the left / centre / right pixel
-        const int xc = valid ? x : sx0;
-        const int pl = (reflect1(xc - 1, W) - sx0) * C, pc = (xc - sx0) * C,
-                  pr = (reflect1(xc + 1, W) - sx0) * C;
-        uint32_t acc[C];
-#pragma unroll
-        for (int c = 0; c < C; c++)
-            acc[c] = 32768u;
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-            const int r = wave + j;
-            const int gy = clampi(reflect1(y0 - 1 + r, H), 0, H - 1);
-            const int mis = (int)((uintptr_t)(fimg + ((size_t)gy * W + sx0) * C) & 3);
-            const uint32_t *row = tile + r * ROWD;
-            // C consecutive bytes starting at byte offset o of the staged row
-            auto px = [&](int o) -> uint32_t {
-                o += mis;
-                const uint32_t lo = row[o >> 2], hi = row[(o >> 2) + 1];
-                return __builtin_amdgcn_alignbyte(hi, lo, (unsigned)(o & 3));
-            };
-            const uint32_t L = px(pl), Cn = px(pc), R = px(pr);
-#pragma unroll
-            for (int c = 0; c < C; c++) {
-                const uint32_t hsum = kx0 * ((L >> (8 * c)) & 255u) + kx1 * ((Cn >> (8 * c)) & 255u) +
-                                      kx2 * ((R >> (8 * c)) & 255u);
-                acc[c] += ky[j] * hsum;
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < C; c++)
-            xin[c] = (float)(acc[c] >> 16);
-    } else {
-        const uint8_t *fp = fimg + ((size_t)yy * W + xl) * C;
-#pragma unroll
-        for (int c = 0; c < C; c++)
-            xin[c] = (float)fp[c];
-    }
-    if (!valid)
-        return;
-
-    // ---- wave-uniform split: does any pixel of this wave carry a second mode? ----
-    uint8_t out;
-    if (__builtin_amdgcn_ballot_w64(nmodes > 1) == 0) {
-        // single-mode wave: nothing more to load; at most slots 0..1 are live afterwards
-#pragma unroll
-        for (int m = 1; m < kMaxModes; m++) {
-            M.w[m] = 0.f;
-            M.var[m] = 0.f;
-#pragma unroll
-            for (int c = 0; c < C; c++)
-                M.mu[m][c] = 0.f;
-        }
-        if (dbg & 1) {
-            out = (uint8_t)(xin[0] + M.w[0]);
-        } else {
-            out = mog2_update<C, 1>(M, nmodes, xin, k);
-        }
-#pragma unroll
-        for (int m = 0; m < 2; m++) {
-            if (m < nmodes && !(dbg & 2)) {
-                float *pm = prow + (size_t)m * F * np;
-                pm[xl] = M.w[m];
-                (pm + np)[xl] = M.var[m];
-#pragma unroll
-                for (int c = 0; c < C; c++)
-                    (pm + (size_t)(2 + c) * np)[xl] = M.mu[m][c];
-            }
-        }
-    } else {
-        // remaining modes, predicated on the pixel's own mode count
+    // remaining modes only if some pixel of the wave has one (wave-uniform split)
+    if (__builtin_amdgcn_ballot_w64(nmodes > 1) != 0) {
 #pragma unroll
         for (int m = 1; m < kMaxModes; m++) {
             if (m < nmodes) {
@@ -408,26 +364,132 @@ __global__ __launch_bounds__(256) void mog2_kernel(const uint8_t *__restrict__ f
                     M.mu[m][c] = 0.f;
             }
         }
-        if (dbg & 1) {
-            out = (uint8_t)(xin[0] + M.w[0] + M.w[1] + M.w[2] + M.w[3] + M.w[4]);
-        } else {
-            out = mog2_update<C, kMaxModes>(M, nmodes, xin, k);
-        }
+    } else {
 #pragma unroll
-        for (int m = 0; m < kMaxModes; m++) {
-            if (m < nmodes && !(dbg & 2)) {
-                float *pm = prow + (size_t)m * F * np;
-                pm[xl] = M.w[m];
-                (pm + np)[xl] = M.var[m];
+        for (int m = 1; m < kMaxModes; m++) {
+            M.w[m] = 0.f;
+            M.var[m] = 0.f;
 #pragma unroll
-                for (int c = 0; c < C; c++)
-                    (pm + (size_t)(2 + c) * np)[xl] = M.mu[m][c];
-            }
+            for (int c = 0; c < C; c++)
+                M.mu[m][c] = 0.f;
         }
     }
-    if (!(dbg & 4))
-        modes[rowoff + xl] = (uint8_t)nmodes;
-    mask[rowoff + xl] = out;
+
+    const int kx0 = (int)(kx012 & 1023), kx1 = (int)((kx012 >> 10) & 1023), kx2 = (int)(kx012 >> 20);
+    const int ky[3] = {(int)(ky012 & 1023), (int)((ky012 >> 10) & 1023), (int)(ky012 >> 20)};
+    // byte offsets (within a staged row) of the left / centre / right pixel
+    const int xc = valid ? x : sx0;
+    const int pl = (reflect1(xc - 1, W) - sx0) * C, pc = (xc - sx0) * C,
+              pr = (reflect1(xc + 1, W) - sx0) * C;
+
+    if (BLUR3)
+        __syncthreads();   // the only barrier: all tiles are in LDS
+
+    // blurred (or raw) pixel of frame ti as floats
+    auto frame_input = [&](int ti, float (&xin)[C]) {
+        const uint8_t *fimg = frame + (size_t)ti * frame_stride + (size_t)img * N * C;
+        if (BLUR3) {
+            const uint32_t *tile = tiles + ti * TILE;
+            uint32_t acc[C];
+#pragma unroll
+            for (int c = 0; c < C; c++)
+                acc[c] = 32768u;
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                const int r = wave + j;
+                const int gy = reflect1(y0 - 1 + r, H);
+                const int gyc = gy < H ? gy : H - 1;
+                const int mis = (int)((uintptr_t)(fimg + ((size_t)gyc * W + sx0) * C) & 3);
+                const uint32_t *row = tile + r * ROWD;
+                // C consecutive bytes starting at byte offset o of the staged row
+                auto px = [&](int o) -> uint32_t {
+                    o += mis;
+                    const uint32_t lo = row[o >> 2], hi = row[(o >> 2) + 1];
+                    return __builtin_amdgcn_alignbyte(hi, lo, (unsigned)(o & 3));
+                };
+                const uint32_t L = px(pl), Cn = px(pc), R = px(pr);
+                // horizontal pass on u16 pairs: the sums are exact in 16 bits
+                // (taps add to 256), two channels per v_pk_mad_u16
+                const uint32_t kk0 = (uint32_t)kx0 * 0x00010001u, kk1 = (uint32_t)kx1 * 0x00010001u,
+                               kk2 = (uint32_t)kx2 * 0x00010001u;
+                auto lo2 = [](uint32_t v) { return __builtin_amdgcn_perm(0u, v, 0x0C010C00u); };   // (b0, b1)
+                auto hi2 = [](uint32_t v) { return __builtin_amdgcn_perm(0u, v, 0x0C030C02u); };   // (b2, b3)
+                uint32_t h01 = pk_mad_u16(lo2(R), kk2, pk_mad_u16(lo2(Cn), kk1, pk_mul_u16(lo2(L), kk0)));
+                acc[0] += ky[j] * (h01 & 0xFFFFu);
+                if (C > 1)
+                    acc[1] += ky[j] * (h01 >> 16);
+                if (C > 2) {
+                    uint32_t h23 = pk_mad_u16(hi2(R), kk2, pk_mad_u16(hi2(Cn), kk1, pk_mul_u16(hi2(L), kk0)));
+                    acc[2] += ky[j] * (h23 & 0xFFFFu);
+                    if (C > 3)
+                        acc[3 % C] += ky[j] * (h23 >> 16);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < C; c++)
+                xin[c] = (float)(acc[c] >> 16);
+        } else {
+            const uint8_t *fp = fimg + ((size_t)yy * W + xl) * C;
+#pragma unroll
+            for (int c = 0; c < C; c++)
+                xin[c] = (float)fp[c];
+        }
+    };
+    // per-frame learning rate (host-computed, wave-uniform select over ti)
+    auto frame_consts = [&](int ti) -> Mog2Consts {
+        Mog2Consts kt = k;
+        if (MULTI) {
+            float a = k.alphaT_f[0], pr = k.prune_f[0];
+#pragma unroll
+            for (int q = 1; q < kMaxT; q++) {
+                a = ti == q ? k.alphaT_f[q] : a;
+                pr = ti == q ? k.prune_f[q] : pr;
+            }
+            kt.alphaT = a;
+            kt.alpha1 = 1.f - a;
+            kt.prune = pr;
+        }
+        return kt;
+    };
+
+    // Two frame loops instead of one with a branch inside: while no pixel of the
+    // wave has a second mode (four waves out of five, and it stays that way for
+    // whole launches) only slots 0..1 are live, so that loop carries a fraction of
+    // the registers; the first frame that sees a second mode anywhere in the wave
+    // hands the rest of the launch to the general loop.
+    int ti = 0;
+    for (; ti < T; ti++) {
+        if (__builtin_amdgcn_ballot_w64(nmodes > 1) != 0)
+            break;
+        float xin[C];
+        frame_input(ti, xin);
+        const Mog2Consts kt = frame_consts(ti);
+        if (valid)
+            mask[(size_t)ti * mask_stride + rowoff + xl] = mog2_update<C, 1>(M, nmodes, xin, kt);
+    }
+    for (; ti < T; ti++) {
+        float xin[C];
+        frame_input(ti, xin);
+        const Mog2Consts kt = frame_consts(ti);
+        if (valid)
+            mask[(size_t)ti * mask_stride + rowoff + xl] =
+                mog2_update<C, kMaxModes>(M, nmodes, xin, kt);
+    }
+    if (!valid)
+        return;
+
+#pragma unroll
+    for (int m = 0; m < kMaxModes; m++) {
+        if (m < nmodes) {
+            float *pm = prow + (size_t)m * F * np;
+            pm[xl] = M.w[m];
+            (pm + np)[xl] = M.var[m];
+#pragma unroll
+            for (int c = 0; c < C; c++)
+                (pm + (size_t)(2 + c) * np)[xl] = M.mu[m][c];
+        }
+    }
+    modes[rowoff + xl] = (uint8_t)nmodes;
 }
 
 // ---------------------------------------------------------------------------
@@ -1144,11 +1206,11 @@ hipError_t blur_sep_q8(const uint8_t *src, uint8_t *dst, int n_img, int h, int w
 }
 
 hipError_t mog2_apply(const uint8_t *frame, uint8_t *mask, const Mog2State &st, int n_img, int h,
-                      int w, int c, const Mog2Consts &k, bool fused_blur3, const Taps &t,
+                      int w, int c, int T, const Mog2Consts &k, bool fused_blur3, const Taps &t,
                       hipStream_t s)
 {
-    if (n_img < 1 || h < 1 || w < 1 || n_img > 65535 || st.np < (size_t)n_img * h * w ||
-        k.nmix < 1 || k.nmix > kMaxModes)
+    if (n_img < 1 || h < 1 || w < 1 || (h + TH - 1) / TH > 65535 || n_img > 65535 ||
+        st.np < (size_t)n_img * h * w || k.nmix < 1 || k.nmix > kMaxModes || T < 1 || T > kMaxT)
         return hipErrorInvalidValue;
     if (fused_blur3 && (t.nkx != 3 || t.nky != 3))
         return hipErrorInvalidValue;
@@ -1157,18 +1219,18 @@ hipError_t mog2_apply(const uint8_t *frame, uint8_t *mask, const Mog2State &st, 
         kx = t.kx[0] | (t.kx[1] << 10) | (t.kx[2] << 20);
         ky = t.ky[0] | (t.ky[1] << 10) | (t.ky[2] << 20);
     }
-    // 1-D tile index per image, padded to a multiple of 8 for the XCD swizzle
-    const long ntiles = (long)((w + TW - 1) / TW) * ((h + TH - 1) / TH);
-    if (ntiles > 0x7ffffff0L)
-        return hipErrorInvalidValue;
-    // both knobs are re-read per launch so that a bench can flip them after its warm-up
-    const int swz = (getenv("GOF_XCD_SWIZZLE") ? atoi(getenv("GOF_XCD_SWIZZLE")) & 255 : 0) |
-                    (getenv("GOF_ABLATE") ? atoi(getenv("GOF_ABLATE")) << 8 : 0);
-    const long span = (swz & 255) > 1 ? 8L * (swz & 255) : 8;
-    dim3 g((unsigned)(((ntiles + span - 1) / span) * span), (unsigned)n_img, 1);
-#define GOF_LAUNCH_MOG2(CC, BB)                                                              \
-    hipLaunchKernelGGL((mog2_kernel<CC, BB>), g, dim3(256), 0, s, frame, mask, st.planes,    \
-                       st.modes, st.np, h, w, k, kx, ky, swz)
+    // frames [T][n_img][h][w][c], masks [T][n_img][h][w]
+    const size_t fstride = (size_t)n_img * h * w * c, mstride = (size_t)n_img * h * w;
+    dim3 g = grid3(w, h, n_img, TW, TH);
+#define GOF_LAUNCH_MOG2(CC, BB)                                                                  \
+    do {                                                                                         \
+        if (T == 1)                                                                              \
+            hipLaunchKernelGGL((mog2_kernel<CC, BB, false>), g, dim3(256), 0, s, frame, mask,    \
+                               st.planes, st.modes, st.np, h, w, T, fstride, mstride, k, kx, ky); \
+        else                                                                                     \
+            hipLaunchKernelGGL((mog2_kernel<CC, BB, true>), g, dim3(256), 0, s, frame, mask,     \
+                               st.planes, st.modes, st.np, h, w, T, fstride, mstride, k, kx, ky); \
+    } while (0)
     if (fused_blur3) {
         switch (c) {
         case 1: GOF_LAUNCH_MOG2(1, true); break;

@@ -86,12 +86,27 @@ class ForegroundPipeline:
         _lib.check(_lib.load().gof_pipeline_apply_host(self._h, _lib.p8(x), _lib.p8(out)))
         return out[0] if single else out
 
+    def apply_many(self, frames):
+        """T consecutive frames of every stream in one call (temporal blocking: the
+        MOG2 model crosses HBM once per 8 frames).  frames: (T, streams, h, w[, c])
+        or (T, h, w[, c]) for one stream; returns the T x streams masks, identical
+        to T calls of apply()."""
+        x = _lib.as_u8(frames, "frames")
+        per = self.streams * self.h * self.w * self.c
+        if x.ndim < 3 or x.size % per or x.size // per != x.shape[0]:
+            raise ValueError("Input shape has changed.")
+        T = x.shape[0]
+        out = np.empty((T, self.streams, self.h, self.w), np.uint8)
+        _lib.check(_lib.load().gof_pipeline_apply_host_many(self._h, _lib.p8(x), _lib.p8(out), T))
+        return out[:, 0] if self.streams == 1 else out
+
     # -- device buffers (bench / serving loop) -------------------------------
-    def apply_device(self, frames_ptr, masks_ptr, stream=None):
-        """Enqueue one step on device pointers (ints); does not synchronise."""
-        _lib.check(_lib.load().gof_pipeline_apply_dev(self._h, C.c_void_p(frames_ptr),
-                                                      C.c_void_p(masks_ptr),
-                                                      C.c_void_p(stream) if stream else None))
+    def apply_device(self, frames_ptr, masks_ptr, stream=None, n_frames=1):
+        """Enqueue one step of n_frames frames per stream on device pointers (ints);
+        does not synchronise."""
+        _lib.check(_lib.load().gof_pipeline_apply_dev_many(
+            self._h, C.c_void_p(frames_ptr), C.c_void_p(masks_ptr), int(n_frames),
+            C.c_void_p(stream) if stream else None))
 
     @property
     def stream(self):
@@ -105,11 +120,13 @@ class ForegroundPipeline:
         _lib.check(_lib.load().gof_pipeline_mean_modes(self._h, C.byref(v)))
         return v.value
 
-    def algorithmic_bytes(self, mean_modes):
-        """(total, detector-kernel) algorithmic HBM bytes of one step."""
+    def algorithmic_bytes(self, mean_modes, n_frames=1):
+        """(total, detector-kernel) algorithmic HBM bytes of one step of n_frames
+        frames per stream."""
         t, k = C.c_double(), C.c_double()
         _lib.check(_lib.load().gof_pipeline_algorithmic_bytes(self._h, float(mean_modes),
-                                                              C.byref(t), C.byref(k)))
+                                                              int(n_frames), C.byref(t),
+                                                              C.byref(k)))
         return t.value, k.value
 
     def profile(self, enable, capacity=0):

@@ -304,6 +304,53 @@ def test_pipeline_streams_are_independent(oracle):
             assert np.array_equal(got[s], refs[s].apply(frames[s]))
 
 
+@pytest.mark.parametrize("T", [1, 2, 3, 8, 11])
+def test_pipeline_temporal_blocking(oracle, T):
+    """apply_many(T frames) == T x apply(): the model stays in registers across
+    the frames of one launch (8 per launch; 11 = one full + one partial launch),
+    masks AND final model state bit-identical to the frame-by-frame oracle."""
+    from pygofpid_amd.foreground import ForegroundPipeline
+    S, h, w, c = 2, 46, 70, 3
+    clips = [Clip(h, w, c, seed=30 + s, n_objects=3) for s in range(S)]
+    gpu = ForegroundPipeline((h, w, c), streams=S)
+    refs = [oracle.Pipeline(h, w, c) for _ in range(S)]
+    t = 0
+    for _ in range(4):
+        frames = np.stack([np.stack([cl.frame(t + i) for cl in clips]) for i in range(T)])
+        got = gpu.apply_many(frames)
+        assert got.shape == (T, S, h, w)
+        for i in range(T):
+            for s in range(S):
+                want = refs[s].apply(frames[i, s])
+                assert np.array_equal(got[i, s], want), (t + i, s)
+        t += T
+    assert abs(gpu.mean_modes() - np.mean([r.mean_modes() for r in refs])) < 1e-12
+    assert gpu.mog2_state()["nframes"] == t
+
+
+def test_pipeline_temporal_blocking_other_paths(oracle):
+    """apply_many through the unfused blur, the FD detector and a grey stream."""
+    from pygofpid_amd.foreground import ForegroundPipeline
+    h, w = 40, 52
+    for kind in ("blur5", "fd", "gray"):
+        c = 1 if kind == "gray" else 3
+        clip = Clip(h, w, c, seed=40, n_objects=2)
+        if kind == "blur5":
+            gpu = ForegroundPipeline((h, w, c), blur=(5, 5, 4.0))
+            ref = oracle.Pipeline(h, w, c, blur_k=5, blur_sigma=4.0)
+        elif kind == "fd":
+            gpu = ForegroundPipeline((h, w, c), detector="FD", fd_threshold=6)
+            ref = oracle.Pipeline(h, w, c, detector="FD", fd_thr=6)
+        else:
+            gpu = ForegroundPipeline((h, w, c))
+            ref = oracle.Pipeline(h, w, c)
+        for r in range(3):
+            frames = np.stack(clip.frames(5, start=5 * r))
+            got = gpu.apply_many(frames)
+            for i in range(5):
+                assert np.array_equal(got[i], ref.apply(frames[i])), (kind, r, i)
+
+
 def test_pipeline_full_hd_bit_exact(oracle):
     """BASELINE config 2 geometry, a few frames against the oracle."""
     from pygofpid_amd.foreground import ForegroundPipeline
