@@ -1,5 +1,5 @@
 """Condenses rocprofv3 CSV output (kernel trace + PMC passes) into a short text
-summary and a traffic JSON that bench.py can cite.  usage: summarize.py <dir>"""
+summary and a traffic JSON that bench.py can cite.  usage: summarize.py <dir> [frames_per_step]"""
 import csv
 import glob
 import json
@@ -20,7 +20,7 @@ def short(name):
     return name.split("(")[0][:70]
 
 
-def main(d):
+def main(d, fps=8):
     # kernel trace: durations per kernel
     dur = defaultdict(list)
     for r in rows(os.path.join(d, "trace", "**", "*kernel_trace.csv")):
@@ -56,7 +56,7 @@ def main(d):
             # reports 1/2 of the bytes of a wide coalesced streaming read -> x2.
             fetch_raw = cs["FETCH_SIZE"] * 1024.0
             write = cs["WRITE_SIZE"] * 1024.0
-            rec = {"config": {"streams": 8, "height": 1080, "width": 1920, "frames_per_step": 1},   # bench.py defaults
+            rec = {"config": {"streams": 8, "height": 1080, "width": 1920, "frames_per_step": fps},
                    "kernel": k, "fetch_size_raw_bytes": fetch_raw, "fetch_bytes_corrected": 2 * fetch_raw,
                    "write_bytes": write, "hbm_bytes_per_launch": 2 * fetch_raw + write,
                    "note": "per launch, mean of the last half of the dispatches; FETCH_SIZE x2 per "
@@ -68,4 +68,4 @@ def main(d):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 8)
