@@ -68,6 +68,53 @@ __device__ __forceinline__ void swap_modes(PixelModel<C> &M, int i, bool doit)
     }
 }
 
+// detectShadowGMM [OPENCV-RECALL] over the first LIM slots, on the model AFTER
+// this frame's update.  Returns true for a shadow pixel.
+template <int C, int LIM>
+__device__ __forceinline__ bool shadow_test(const PixelModel<C> &M, int nmodes, const float (&x)[C],
+                                            const Mog2Consts &k)
+{
+    bool shadow = false;
+    if (k.detect_shadows) {
+        float tW = 0.f;
+        bool done = false;
+#pragma unroll
+        for (int m = 0; m < LIM; m++) {
+            if (!done && m < nmodes) {
+                float num = 0.f, den = 0.f;
+#pragma unroll
+                for (int c = 0; c < C; c++) {
+                    num += x[c] * M.mu[m][c];
+                    den += M.mu[m][c] * M.mu[m][c];
+                }
+                if (den == 0.f) {
+                    done = true;
+                } else {
+                    if (num <= den && num >= k.tau * den) {
+                        float a = num / den;
+                        float dist2a = 0.f;
+#pragma unroll
+                        for (int c = 0; c < C; c++) {
+                            float dD = a * M.mu[m][c] - x[c];
+                            dist2a += dD * dD;
+                        }
+                        if (dist2a < k.Tb * M.var[m] * a * a) {
+                            shadow = true;
+                            done = true;
+                        }
+                    }
+                    if (!done) {
+                        tW += M.w[m];
+                        if (tW > k.TB)
+                            done = true;
+                    }
+                }
+            }
+        }
+    }
+    return shadow;
+}
+
 // One pixel of MOG2Invoker::operator() on a register-resident model.
 // Statement order follows oracle/gof_oracle.c mog2_pixel(); the only
 // re-statement is that the fitted mode's new weight is stored in its slot
@@ -183,45 +230,7 @@ __device__ __forceinline__ uint8_t mog2_update(PixelModel<C> &M, int &nmodes_io,
 
     if (background)
         return 0;
-    bool shadow = false;
-    if (k.detect_shadows) {
-        float tW = 0.f;
-        bool done = false;
-#pragma unroll
-        for (int m = 0; m < LOUT; m++) {
-            if (!done && m < nmodes) {
-                float num = 0.f, den = 0.f;
-#pragma unroll
-                for (int c = 0; c < C; c++) {
-                    num += x[c] * M.mu[m][c];
-                    den += M.mu[m][c] * M.mu[m][c];
-                }
-                if (den == 0.f) {
-                    done = true;
-                } else {
-                    if (num <= den && num >= k.tau * den) {
-                        float a = num / den;
-                        float dist2a = 0.f;
-#pragma unroll
-                        for (int c = 0; c < C; c++) {
-                            float dD = a * M.mu[m][c] - x[c];
-                            dist2a += dD * dD;
-                        }
-                        if (dist2a < k.Tb * M.var[m] * a * a) {
-                            shadow = true;
-                            done = true;
-                        }
-                    }
-                    if (!done) {
-                        tW += M.w[m];
-                        if (tW > k.TB)
-                            done = true;
-                    }
-                }
-            }
-        }
-    }
-    return shadow ? (uint8_t)k.shadow_value : (uint8_t)255;
+    return shadow_test<C, LOUT>(M, nmodes, x, k) ? (uint8_t)k.shadow_value : (uint8_t)255;
 }
 
 typedef unsigned short gof_u16x2 __attribute__((ext_vector_type(2)));
@@ -235,6 +244,93 @@ __device__ __forceinline__ uint32_t pk_mad_u16(uint32_t a, uint32_t b, uint32_t 
     gof_u16x2 r = __builtin_bit_cast(gof_u16x2, a) * __builtin_bit_cast(gof_u16x2, b) +
                   __builtin_bit_cast(gof_u16x2, c);
     return __builtin_bit_cast(uint32_t, r);
+}
+
+// The MAXIN = 1 instance of mog2_update written without per-lane branches on the
+// common path.  Same statements on the same values (every lane evaluates the fit
+// arithmetic, selects keep it only where the reference would have executed it);
+// the rare parts -- inserting a new mode, the shadow test of a non-background
+// pixel -- sit behind wave-uniform branches.  On a wave of pure background this
+// is a straight line of ~70 vector instructions and no exec-mask bookkeeping,
+// which matters because the multi-frame kernel is bound by VALU + SALU issue.
+template <int C>
+__device__ __forceinline__ uint8_t mog2_update_single(PixelModel<C> &M, int &nmodes_io,
+                                                      const float (&x)[C], const Mog2Consts &k)
+{
+    int nmodes = nmodes_io;               // 0 or 1 on entry
+    const bool has = nmodes > 0;
+    const float var = M.var[0];
+    const float weight = k.alpha1 * M.w[0] + k.prune;
+    float d[C];
+    float dist2;
+    if (C == 3) {
+        d[0] = M.mu[0][0] - x[0];
+        d[1] = M.mu[0][1] - x[1];
+        d[2] = M.mu[0][2] - x[2];
+        dist2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+    } else {
+        dist2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            d[c] = M.mu[0][c] - x[c];
+            dist2 += d[c] * d[c];
+        }
+    }
+    const bool background = has && 0.f < k.TB && dist2 < k.Tb * var;
+    const bool fit = has && dist2 < k.Tg * var;
+    const float wfit = weight + k.alphaT;
+    const float kk = k.alphaT / wfit;
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+        const float mnew = M.mu[0][c] - kk * d[c];
+        M.mu[0][c] = fit ? mnew : M.mu[0][c];
+    }
+    float varnew = var + kk * (dist2 - var);
+    varnew = varnew > k.var_min ? varnew : k.var_min;
+    varnew = varnew > k.var_max ? k.var_max : varnew;
+    M.var[0] = fit ? varnew : var;
+    const float w2 = fit ? wfit : weight;
+    const bool pruned = has && w2 < -k.prune;
+    const float wstore = pruned ? 0.f : w2;
+    nmodes -= pruned ? 1 : 0;
+    const float total = has ? 0.f + wstore : 0.f;
+    float inv = 0.f;
+    if (fabsf(total) > FLT_EPSILON)
+        inv = 1.f / total;
+    {
+        const float wn = nmodes > 0 ? wstore * inv : wstore;
+        M.w[0] = has ? wn : M.w[0];
+    }
+
+    const bool need = !fit && k.alphaT > 0.f;
+    if (__builtin_amdgcn_ballot_w64(need) != 0) {   // wave-uniform: some pixel opens a new mode
+        if (need) {
+            const int slot = nmodes == k.nmix ? k.nmix - 1 : nmodes++;
+            const bool first = nmodes == 1;
+#pragma unroll
+            for (int m = 0; m < 2; m++) {
+                if (m == slot) {
+                    M.w[m] = first ? 1.f : k.alphaT;
+                    M.var[m] = k.var_init;
+#pragma unroll
+                    for (int c = 0; c < C; c++)
+                        M.mu[m][c] = x[c];
+                } else if (!first && m < nmodes - 1) {
+                    M.w[m] *= k.alpha1;
+                }
+            }
+            const bool sw = 1 <= nmodes - 1 && !(k.alphaT < M.w[0]);
+            swap_modes<C>(M, 1, sw);
+        }
+    }
+    nmodes_io = nmodes;
+
+    uint8_t out = 0;
+    if (__builtin_amdgcn_ballot_w64(!background) != 0) {   // wave-uniform: some pixel is not background
+        if (!background)
+            out = shadow_test<C, 2>(M, nmodes, x, k) ? (uint8_t)k.shadow_value : (uint8_t)255;
+    }
+    return out;
 }
 
 // REFLECT_101 for a reach of one pixel: -1 -> 1, len -> len-2 (len == 1 -> 0)
@@ -465,7 +561,7 @@ __global__ __launch_bounds__(256) void mog2_kernel(const uint8_t *__restrict__ f
         frame_input(ti, xin);
         const Mog2Consts kt = frame_consts(ti);
         if (valid)
-            mask[(size_t)ti * mask_stride + rowoff + xl] = mog2_update<C, 1>(M, nmodes, xin, kt);
+            mask[(size_t)ti * mask_stride + rowoff + xl] = mog2_update_single<C>(M, nmodes, xin, kt);
     }
     for (; ti < T; ti++) {
         float xin[C];
