@@ -37,7 +37,7 @@ os.environ.setdefault("OMP_WAIT_POLICY", "active")
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-def make_pool(torch, streams, pool, h, w, device, seed):
+def make_pool(torch, streams, pool, h, w, device, seed, n_objects=6):
     """[pool][streams][h][w][3] uint8 on the device: BASELINE.md section 3 recipe
     (gradient + texture background, N(0,2) noise, +60 rectangles moving 3 px per
     frame with a 0.7x shadow patch beside each)."""
@@ -53,7 +53,7 @@ def make_pool(torch, streams, pool, h, w, device, seed):
         tex = torch.randint(-12, 13, (h, w), generator=g, device=device).float()
         bg = (grad + tex)[..., None] * tint
         objs = []
-        for _ in range(6):
+        for _ in range(n_objects):
             objs.append((int(torch.randint(0, w, (1,), generator=g, device=device)),
                          int(torch.randint(0, max(1, h - oh), (1,), generator=g, device=device)),
                          1 if float(torch.rand(1, generator=g, device=device)) < 0.5 else -1))
@@ -124,6 +124,7 @@ def main():
     ap.add_argument("--frames-per-step", type=int, default=8,
                     help="consecutive frames of every stream handed over per step (temporal "
                          "blocking: the MOG2 model crosses HBM once per 8 frames)")
+    ap.add_argument("--objects", type=int, default=6, help="moving rectangles per stream")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="0 disables the CPU leg")
     ap.add_argument("--traffic-file", default=os.path.join(ROOT, "profiles", "traffic_latest.json"))
     ap.add_argument("--no-events", action="store_true",
@@ -151,7 +152,7 @@ def main():
     T = args.frames_per_step
     if T < 1 or args.pool % T:
         raise SystemExit("--frames-per-step must divide --pool")
-    frames = make_pool(torch, S, args.pool, h, w, device, seed=17 + rank)
+    frames = make_pool(torch, S, args.pool, h, w, device, seed=17 + rank, n_objects=args.objects)
     masks = torch.empty((T, S, h, w), dtype=torch.uint8, device=device)
     torch.cuda.synchronize()
 
@@ -254,7 +255,7 @@ def main():
                 "morph_kernel_us": round(morph_ms / n_meas * 1e3, 2),
                 "whole_step_GBps": round(total_b / (elapsed / K) / 1e9, 1),
             }
-        if args.cpu_seconds > 0:
+        if args.cpu_seconds > 0 and world == 1:   # CPU leg: rank 0 at N = 1 only
             host = [frames[i, 0].cpu().numpy() for i in range(P)]
             out["cpu_baseline"] = cpu_baseline(host, h, w, args.cpu_seconds)
         print(json.dumps(out), flush=True)

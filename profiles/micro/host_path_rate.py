@@ -1,0 +1,33 @@
+"""End-to-end (host buffer in, host mask out) rate of the drop-in path at 1080p:
+what GOFPID.detect() pays on top of the kernels is PCIe (6.2 MB in + 2.1 MB out
+per frame) and, for detect(), the host-side steps 4-7."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np
+from pygofpid_amd.foreground import ForegroundPipeline
+from pygofpid_amd.pipeline import GOFPID
+from pygofpid_amd.synth import Clip
+
+h, w = 1080, 1920
+clip = Clip(h, w, 3, seed=17)
+frames = np.stack(clip.frames(16))
+p = ForegroundPipeline((h, w, 3))
+for f in frames[:4]:
+    p.apply(f)
+t0 = time.perf_counter(); n = 0
+while time.perf_counter() - t0 < 3:
+    p.apply(frames[n % 16]); n += 1
+print("ForegroundPipeline.apply      (1 frame / call, pageable host memory): %.0f frames/s" % (n / (time.perf_counter() - t0)))
+p8 = ForegroundPipeline((h, w, 3))
+p8.apply_many(frames[:8])
+t0 = time.perf_counter(); n = 0
+while time.perf_counter() - t0 < 3:
+    p8.apply_many(frames[(n % 2) * 8:(n % 2) * 8 + 8]); n += 8
+print("ForegroundPipeline.apply_many (8 frames / call):                       %.0f frames/s" % (n / (time.perf_counter() - t0)))
+g = GOFPID().initialize()
+for f in frames[:4]:
+    g.detect(f)
+t0 = time.perf_counter(); n = 0
+while time.perf_counter() - t0 < 3:
+    g.detect(frames[n % 16]); n += 1
+print("GOFPID.detect (steps 1-3 GPU + steps 4-7 host):                        %.0f frames/s" % (n / (time.perf_counter() - t0)))
