@@ -141,9 +141,15 @@ def main():
         raise SystemExit("launch N > 1 with torch.distributed.run (one process per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback")
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
-    gd.init(backend="nccl", device=device)   # no-op for a single process
+    ndev = torch.cuda.device_count()
+    dev_index = local % max(1, ndev)          # one GPU per rank on the 8-GPU node
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    # RCCL ("nccl") on the GPU node; GOF_DIST_BACKEND=gloo lets several ranks share one
+    # card for rehearsals (RCCL refuses two ranks on the same device)
+    backend = os.environ.get("GOF_DIST_BACKEND", "nccl")
+    gd.init(backend=backend, device=device if backend == "nccl" else None)   # no-op for 1 process
+    red_dev = device if backend == "nccl" else "cpu"
 
     from pygofpid_amd import _lib
     from pygofpid_amd.foreground import ForegroundPipeline
@@ -156,7 +162,7 @@ def main():
     masks = torch.empty((T, S, h, w), dtype=torch.uint8, device=device)
     torch.cuda.synchronize()
 
-    ctx = _lib.Context(local)
+    ctx = _lib.Context(dev_index)
     pipe = ForegroundPipeline((h, w, 3), streams=S, ctx=ctx)
     P = args.pool
 
@@ -183,7 +189,7 @@ def main():
     pipe.synchronize()
     torch.cuda.synchronize()
     gd.barrier()
-    elapsed = gd.max_over_ranks(time.perf_counter() - t0, device=device)
+    elapsed = gd.max_over_ranks(time.perf_counter() - t0, device=red_dev)
 
     det_ms = morph_ms = 0.0
     n_meas = 0

@@ -44,7 +44,7 @@ enum {
 
 enum { GOF_ERODE = 0, GOF_DILATE = 1 };
 enum { GOF_DET_MOG2 = 0, GOF_DET_FD = 1 };
-enum { GOF_BLUR_NONE = 0, GOF_BLUR_GAUSS = 1 };
+enum { GOF_BLUR_NONE = 0, GOF_BLUR_GAUSS = 1, GOF_BLUR_BOX = 2 };
 
 #define GOF_MAX_MODES 5      /* cv2 MOG2 default nmixtures                 */
 #define GOF_MAX_MORPH 8      /* ops in one pipeline's mat_morph list       */
@@ -82,7 +82,7 @@ typedef struct gof_morph_op {
 typedef struct gof_pipeline_desc {
     int streams;              /* independent video streams stepped together (>= 1) */
     int h, w, c;              /* frame geometry, c in {1, 3, 4}            */
-    int blur;                 /* GOF_BLUR_NONE | GOF_BLUR_GAUSS            */
+    int blur;                 /* GOF_BLUR_NONE | GOF_BLUR_GAUSS | GOF_BLUR_BOX */
     int blur_kw, blur_kh;     /* odd                                        */
     double blur_sigma_x, blur_sigma_y;
     int detector;             /* GOF_DET_MOG2 | GOF_DET_FD                 */
@@ -121,6 +121,14 @@ int gof_gaussian_blur_host(gof_ctx *ctx, const uint8_t *src, uint8_t *dst, int h
 int gof_gaussian_blur_dev(gof_ctx *ctx, const void *d_src, void *d_dst, int n_images, int h,
                           int w, int c, int kw, int kh, double sigma_x, double sigma_y,
                           void *stream);
+/* cv.blur(src, (kw, kh)) on uint8: normalised box filter, BORDER_REFLECT_101,
+ * out = round-half-even(sum / (kw*kh)).  The reference's tests call it as
+ * blur['fun'](X, ksize, borderType) (tests/test_pipeline.py:68-75): cv2 binds that
+ * third positional argument to `dst`, so the requested border is ignored. */
+int gof_box_blur_host(gof_ctx *ctx, const uint8_t *src, uint8_t *dst, int h, int w, int c, int kw,
+                      int kh);
+int gof_box_blur_dev(gof_ctx *ctx, const void *d_src, void *d_dst, int n_images, int h, int w,
+                     int c, int kw, int kh, void *stream);
 /* the 8.8 fixed-point taps the blur uses (host only, for tests) */
 int gof_gauss_kernel_q8(int n, double sigma, uint16_t *taps);
 

@@ -96,6 +96,8 @@ def lib():
         L.gofo_gaussian_blur.restype = C.c_int
         L.gofo_cvt_gray.argtypes = [_u8p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int]
         L.gofo_cvt_gray.restype = None
+        L.gofo_box_blur.argtypes = [_u8p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.gofo_box_blur.restype = None
         L.gofo_mog2_default_params.argtypes = [C.POINTER(Mog2Params)]
         L.gofo_mog2_create.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(Mog2Params)]
         L.gofo_mog2_create.restype = C.c_void_p
@@ -148,6 +150,14 @@ def gaussian_blur(x, ksize=(3, 3), sigma_x=4.0, sigma_y=0.0):
     if lib().gofo_gaussian_blur(_p8(x), _p8(out), h, w, c, int(ksize[0]), int(ksize[1]),
                                 float(sigma_x), float(sigma_y)):
         raise ValueError("bad Gaussian ksize %r" % (ksize,))
+    return out
+
+
+def box_blur(x, ksize=(3, 3)):
+    """cv.blur(x, ksize): normalised box filter, REFLECT_101, round-half-even."""
+    x, h, w, c = _as_hwc(x)
+    out = np.empty((h, w) if c == 1 else (h, w, c), dtype=np.uint8)
+    lib().gofo_box_blur(_p8(x), _p8(out), h, w, c, int(ksize[0]), int(ksize[1]))
     return out
 
 
@@ -249,7 +259,7 @@ class MOG2:
 class Pipeline:
     """Steps 1-3 of GOFPID.detect [REF pipeline.py:461-476], threaded over rows.
 
-    blur_k: 0 or odd square ksize; sigma is what the reference passes
+    blur_k: 0 or odd square ksize (negative: box filter of that size); sigma is what the reference passes
     positionally (BORDER_DEFAULT=4 -> sigmaX=4.0).  morph: [('erode', 5), ...]
     with rectangular kernels.
     """

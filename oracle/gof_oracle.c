@@ -237,6 +237,31 @@ int gofo_gaussian_blur(const uint8_t *src, uint8_t *dst, int h, int w, int c,
     return 0;
 }
 
+/* cv.blur(src, (kw, kh)) on uint8: normalised box filter, REFLECT_101.
+ * OpenCV sums the window in int and stores saturate_cast<uchar>(sum * scale)
+ * with scale = 1.0 / (kw*kh) in double, i.e. cvRound (round-half-even) of the
+ * double product [OPENCV-RECALL: box_filter ColumnSum<int, uchar>]. */
+void gofo_box_blur(const uint8_t *src, uint8_t *dst, int h, int w, int c, int kw, int kh)
+{
+    int rx = kw / 2, ry = kh / 2;
+    double scale = 1.0 / ((double)kw * (double)kh);
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < h; y++) {
+        for (int x = 0; x < w; x++) {
+            for (int ch = 0; ch < c; ch++) {
+                int sum = 0;
+                for (int j = -ry; j <= ry; j++) {
+                    const uint8_t *row = src + (size_t)reflect101(y + j, h) * w * c;
+                    for (int i = -rx; i <= rx; i++)
+                        sum += row[(size_t)reflect101(x + i, w) * c + ch];
+                }
+                long v = lrint((double)sum * scale);
+                dst[((size_t)y * w + x) * c + ch] = (uint8_t)(v > 255 ? 255 : v);
+            }
+        }
+    }
+}
+
 /* ------------------------------------------------------------------------- */
 /* MOG2   [OPENCV-RECALL: bgfg_gaussmix2.cpp MOG2Invoker]      */
 /* ------------------------------------------------------------------------- */
@@ -595,7 +620,7 @@ void gofo_morph(int op, const uint8_t *src, uint8_t *dst, int h, int w,
 
 typedef struct gofo_pipeline {
     int h, w, c;
-    int blur_k;          /* 0 = no blur, else odd ksize (square)             */
+    int blur_k;          /* 0 = no blur, else odd ksize (square); < 0: box of -blur_k */
     double blur_sigma;
     int detector;        /* 0 = MOG2, 1 = FD                                  */
     double fd_thr;
@@ -670,7 +695,10 @@ void gofo_pipeline_apply(gofo_pipeline *p, const uint8_t *frame, uint8_t *mask)
     const uint8_t *x = frame;
     uint16_t kx[256];
 
-    if (p->blur_k) {
+    if (p->blur_k < 0) {
+        gofo_box_blur(frame, p->blurred, h, w, c, -p->blur_k, -p->blur_k);
+        x = p->blurred;
+    } else if (p->blur_k) {
         gofo_gauss_kernel_q8(p->blur_k, p->blur_sigma, kx);
         if (p->blur_k == 3) {
 #pragma omp parallel for schedule(static) num_threads(nt)

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("GOFPID_LIB") or os.path.join(_HERE, "csrc", "libgofpi
 OK, EINVAL, EHIP, ENOMEM, ENODEV = 0, 1, 2, 3, 4
 ERODE, DILATE = 0, 1
 DET_MOG2, DET_FD = 0, 1
-BLUR_NONE, BLUR_GAUSS = 0, 1
+BLUR_NONE, BLUR_GAUSS, BLUR_BOX = 0, 1, 2
 MAX_MODES, MAX_MORPH, MAX_KSIZE = 5, 8, 31
 
 _u8p = C.POINTER(C.c_uint8)
@@ -67,6 +67,10 @@ SIGNATURES = {
     "gof_gaussian_blur_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                         C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
                                         C.c_double, C.c_void_p]),
+    "gof_box_blur_host": (C.c_int, [C.c_void_p, _u8p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                    C.c_int]),
+    "gof_box_blur_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                   C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "gof_gauss_kernel_q8": (C.c_int, [C.c_int, C.c_double, _u16p]),
     "gof_mog2_default_params": (None, [C.POINTER(Mog2Params)]),
     "gof_mog2_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,

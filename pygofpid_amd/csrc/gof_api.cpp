@@ -135,6 +135,21 @@ int make_taps(int kw, int kh, double sx, double sy, gofk::Taps *t)
         return fail(GOF_EINVAL, "bad Gaussian kernel");
     t->nkx = kw;
     t->nky = kh;
+    t->box_scale = 0.0;
+    return GOF_OK;
+}
+
+// cv.blur(src, (kw, kh)): normalised box filter, REFLECT_101 [OPENCV-RECALL]
+int make_box(int kw, int kh, gofk::Taps *t)
+{
+    if (kw < 1 || kh < 1 || !(kw & 1) || !(kh & 1) || kw > GOF_MAX_KSIZE || kh > GOF_MAX_KSIZE)
+        return fail(GOF_EINVAL, "box ksize must be odd and in [1, %d], got (%d, %d)",
+                    GOF_MAX_KSIZE, kw, kh);
+    for (int i = 0; i < gofk::kMaxKsize; i++)
+        t->kx[i] = t->ky[i] = 1;
+    t->nkx = kw;
+    t->nky = kh;
+    t->box_scale = 1.0 / ((double)kw * (double)kh);
     return GOF_OK;
 }
 
@@ -354,6 +369,45 @@ int gof_gaussian_blur_dev(gof_ctx *ctx, const void *d_src, void *d_dst, int n_im
     GOF_HIP(hipSetDevice(ctx->device));
     GOF_HIP(gofk::blur_sep_q8((const uint8_t *)d_src, (uint8_t *)d_dst, n_images, h, w, c, t,
                               pick(ctx, stream)));
+    return GOF_OK;
+}
+
+int gof_box_blur_dev(gof_ctx *ctx, const void *d_src, void *d_dst, int n_images, int h, int w,
+                     int c, int kw, int kh, void *stream)
+{
+    if (!ctx || !d_src || !d_dst)
+        return fail(GOF_EINVAL, "NULL argument");
+    if (d_src == d_dst)
+        return fail(GOF_EINVAL, "blur cannot run in place");
+    int rc = check_geom(n_images, h, w, c);
+    if (rc)
+        return rc;
+    gofk::Taps t;
+    if ((rc = make_box(kw, kh, &t)))
+        return rc;
+    GOF_HIP(hipSetDevice(ctx->device));
+    GOF_HIP(gofk::blur_sep_q8((const uint8_t *)d_src, (uint8_t *)d_dst, n_images, h, w, c, t,
+                              pick(ctx, stream)));
+    return GOF_OK;
+}
+
+int gof_box_blur_host(gof_ctx *ctx, const uint8_t *src, uint8_t *dst, int h, int w, int c, int kw,
+                      int kh)
+{
+    if (!ctx || !src || !dst)
+        return fail(GOF_EINVAL, "NULL argument");
+    int rc = check_geom(1, h, w, c);
+    if (rc)
+        return rc;
+    size_t bytes = (size_t)h * w * c;
+    GOF_HIP(hipSetDevice(ctx->device));
+    if ((rc = ctx->in.reserve(bytes)) || (rc = ctx->out.reserve(bytes)))
+        return rc;
+    GOF_HIP(hipMemcpyAsync(ctx->in.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = gof_box_blur_dev(ctx, ctx->in.p, ctx->out.p, 1, h, w, c, kw, kh, nullptr)))
+        return rc;
+    GOF_HIP(hipMemcpyAsync(dst, ctx->out.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    GOF_HIP(hipStreamSynchronize(ctx->stream));
     return GOF_OK;
 }
 
@@ -782,7 +836,7 @@ int gof_pipeline_create(gof_ctx *ctx, const gof_pipeline_desc *desc, gof_pipelin
         return fail(GOF_EINVAL, "n_morph must be in [0, %d]", GOF_MAX_MORPH);
     if (desc->detector != GOF_DET_MOG2 && desc->detector != GOF_DET_FD)
         return fail(GOF_EINVAL, "Unknown method for foreground detection");
-    if (desc->blur != GOF_BLUR_NONE && desc->blur != GOF_BLUR_GAUSS)
+    if (desc->blur != GOF_BLUR_NONE && desc->blur != GOF_BLUR_GAUSS && desc->blur != GOF_BLUR_BOX)
         return fail(GOF_EINVAL, "unknown blur kind %d", desc->blur);
     gof_pipeline *p = new (std::nothrow) gof_pipeline;
     if (!p)
@@ -798,6 +852,9 @@ int gof_pipeline_create(gof_ctx *ctx, const gof_pipeline_desc *desc, gof_pipelin
                             &p->taps)))
             return bail(rc);
         p->fuse_blur3 = desc->detector == GOF_DET_MOG2 && p->taps.nkx == 3 && p->taps.nky == 3;
+    } else if (desc->blur == GOF_BLUR_BOX) {
+        if ((rc = make_box(desc->blur_kw, desc->blur_kh, &p->taps)))
+            return bail(rc);
     }
     bool all_rect = desc->n_morph > 0;
     p->chain.n = desc->n_morph;
@@ -874,7 +931,7 @@ int gof_pipeline_apply_dev_many(gof_pipeline *p, const void *d_frames, void *d_m
 
     // step 1 (pipeline.py:462-467) -- unless it is fused into step 2
     const uint8_t *x = (const uint8_t *)d_frames;
-    if (d.blur == GOF_BLUR_GAUSS && !p->fuse_blur3) {
+    if (d.blur != GOF_BLUR_NONE && !p->fuse_blur3) {
         if ((rc = p->blurred.reserve((size_t)T * npx * d.c)))
             return rc;
         GOF_HIP(gofk::blur_sep_q8(x, (uint8_t *)p->blurred.p, T * d.streams, d.h, d.w, d.c, p->taps, s));
@@ -1046,7 +1103,7 @@ int gof_pipeline_algorithmic_bytes(gof_pipeline *p, double mean_modes, int n_fra
         det += T * 2.0 * d.c;                                  // X_{t-1} read, X_t kept
     }
     double tot = det;
-    if (d.blur == GOF_BLUR_GAUSS && !p->fuse_blur3)
+    if (d.blur != GOF_BLUR_NONE && !p->fuse_blur3)
         tot += T * 2.0 * d.c;                                  // blurred image written + read
     const int morph_kernels = d.n_morph == 0 ? 0 : (p->chain_ok ? 1 : d.n_morph);
     tot += T * 2.0 * morph_kernels;                            // each reads a mask, writes a mask

@@ -41,6 +41,9 @@ struct Taps {
     uint16_t kx[kMaxKsize];
     uint16_t ky[kMaxKsize];
     int nkx, nky;
+    // 0: 8.8 fixed-point taps, out = (sum + 2^15) >> 16.  != 0: normalised box
+    // filter (all taps 1), out = rint(double(sum) * box_scale) as cv.blur does.
+    double box_scale;
 };
 
 struct SeBits {            // structuring element, bit dx of rows[dy] = member

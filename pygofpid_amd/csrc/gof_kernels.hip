@@ -656,7 +656,14 @@ __global__ __launch_bounds__(256) void blur_kernel(const uint8_t *__restrict__ s
         uint8_t *o = dimg + ((size_t)y * W + x) * C;
 #pragma unroll
         for (int c = 0; c < C; c++) {
-            uint32_t v = a[c] >> 16;
+            uint32_t v;
+            if (t.box_scale != 0.0) {
+                // cv.blur: saturate_cast<uchar>(sum * scale) = round-half-even of the
+                // double product [OPENCV-RECALL]; a[c] carries the +2^15 of the other form
+                v = (uint32_t)__double2int_rn((double)(a[c] - 32768u) * t.box_scale);
+            } else {
+                v = a[c] >> 16;
+            }
             o[c] = (uint8_t)(v > 255u ? 255u : v);
         }
     }

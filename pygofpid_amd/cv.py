@@ -102,6 +102,27 @@ def GaussianBlur(src, ksize, sigmaX, dst=None, sigmaY=0, borderType=BORDER_DEFAU
     return out
 
 
+def blur(src, ksize, dst=None, anchor=(-1, -1), borderType=BORDER_DEFAULT):
+    """cv.blur: normalised box filter on uint8, REFLECT_101, round-half-even.
+
+    Positional order is cv2's.  The reference calls
+    `blur['fun'](X, blur['ksize'], blur['borderType'])` (pipeline.py:463-467) and its
+    tests pass cv.blur there (tests/test_pipeline.py:68-75): cv2 binds that third
+    argument to `dst`, so the border it names is ignored -- and so it is here.
+    """
+    if borderType not in (BORDER_DEFAULT, BORDER_REFLECT_101):
+        raise ValueError("only BORDER_REFLECT_101 (the reference's effective border) is built")
+    if anchor not in ((-1, -1), None):
+        raise ValueError("only the centre anchor is built")
+    x = _lib.as_u8(src, "src")
+    x, h, w, c = _lib.hwc(x)
+    out = np.empty((h, w) if c == 1 else (h, w, c), np.uint8)
+    ctx = _lib.default_context()
+    _lib.check(_lib.load().gof_box_blur_host(ctx.handle, _lib.p8(x), _lib.p8(out), h, w, c,
+                                             int(ksize[0]), int(ksize[1])))
+    return out
+
+
 def _morph(op, src, kernel):
     x = _lib.as_u8(src, "src")
     if x.ndim == 3 and x.shape[2] == 1:

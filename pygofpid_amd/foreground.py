@@ -20,6 +20,7 @@ class ForegroundPipeline:
     shape : (h, w) | (h, w, c)
     streams : number of independent streams stepped per call
     blur : None | (kw, kh, sigma_x[, sigma_y])   -- Gaussian, REFLECT_101
+           | ('box', kw, kh)                     -- cv.blur, REFLECT_101
     detector : 'MOG2' | 'FD'
     morph : list of (op, kernel) with op in {'erode', 'dilate'} and kernel a
         (kh, kw) array (non-zero = member)
@@ -38,6 +39,9 @@ class ForegroundPipeline:
         d.streams, d.h, d.w, d.c = self.streams, self.h, self.w, self.c
         if blur is None:
             d.blur = _lib.BLUR_NONE
+        elif blur[0] == 'box':
+            d.blur = _lib.BLUR_BOX
+            d.blur_kw, d.blur_kh = int(blur[1]), int(blur[2])
         else:
             d.blur = _lib.BLUR_GAUSS
             d.blur_kw, d.blur_kh = int(blur[0]), int(blur[1])

@@ -164,12 +164,16 @@ class GOFPID():
         """(blur, detector, morph) arguments of a ForegroundPipeline, or None when
         the configuration contains callables that are not this package's."""
         if self.blur:
-            if self.blur.get('fun') is not cv.GaussianBlur:
-                return None
             kw, kh = self.blur.get('ksize')
-            # reference call convention: borderType arrives as sigmaX (pipeline.py:463-467)
-            blur = (int(kw), int(kh), float(self.blur.get('borderType')))
             if kw < 1 or kh < 1 or kw % 2 == 0 or kh % 2 == 0:
+                return None
+            if self.blur.get('fun') is cv.GaussianBlur:
+                # reference call convention: borderType arrives as sigmaX (pipeline.py:463-467)
+                blur = (int(kw), int(kh), float(self.blur.get('borderType')))
+            elif self.blur.get('fun') is cv.blur:
+                # ... and as `dst` for cv.blur: ignored
+                blur = ('box', int(kw), int(kh))
+            else:
                 return None
         else:
             blur = None

@@ -62,18 +62,22 @@ def test_cvtcolor_values(cv, oracle):
 
 
 @pytest.mark.parametrize("size", [(64, 50), (64, 32, 1), (32, 20, 3)])
-@pytest.mark.parametrize("blur", ["none", "gauss", "gauss_default_keys", "gauss5"])
+@pytest.mark.parametrize("blur", ["none", "gauss", "gauss_default_keys", "gauss5", "box_replicate",
+                                  "box"])
 def test_gofpid_blur(G, cv, oracle, size, blur):
-    """reference :58-86 (its cv.blur cases are the box filter, SURVEY.md 8(f) next #2)"""
+    """reference :58-86, all four of its blur configurations plus two more"""
     cfg = {"none": None,
            "gauss": {'fun': cv.GaussianBlur, 'ksize': (3, 3), 'borderType': cv.BORDER_DEFAULT},
            "gauss_default_keys": {'fun': cv.GaussianBlur},
-           "gauss5": {'fun': cv.GaussianBlur, 'ksize': (5, 5), 'borderType': cv.BORDER_DEFAULT}}[blur]
+           "gauss5": {'fun': cv.GaussianBlur, 'ksize': (5, 5), 'borderType': cv.BORDER_DEFAULT},
+           "box_replicate": {'fun': cv.blur, 'borderType': cv.BORDER_REPLICATE},
+           "box": {'fun': cv.blur, 'ksize': (3, 3)}}[blur]
     gofpid = G(blur=cfg, post_filter=post_filter.copy()).initialize()
     np.random.seed(17)
     h, w = size[:2]
     c = 1 if len(size) == 2 else size[2]
-    ref = oracle.Pipeline(h, w, c, blur_k={"none": 0, "gauss5": 5}.get(blur, 3), blur_sigma=4.0)
+    ref = oracle.Pipeline(h, w, c, blur_sigma=4.0,
+                          blur_k={"none": 0, "gauss5": 5, "box": -3, "box_replicate": -3}.get(blur, 3))
     for _ in range(3):
         img = np.random.randint(0, high=255, size=size, dtype=np.uint8)
         gofpid.detect(img)

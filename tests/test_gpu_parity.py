@@ -70,6 +70,18 @@ def test_gaussian_blur_full_hd(cv, oracle):
     assert (cv.GaussianBlur(c, (5, 5), 4) == 201).all()
 
 
+@pytest.mark.parametrize("shape", [(64, 50), (64, 32, 1), (32, 20, 3), (1, 1), (3, 70, 3), (130, 200, 3)])
+@pytest.mark.parametrize("ks", [(3, 3), (5, 5), (3, 7), (1, 1), (31, 31)])
+def test_box_blur(cv, oracle, shape, ks):
+    """cv.blur (SURVEY.md 8(f) next #2; reference tests/test_pipeline.py:68-75)."""
+    x = _rng(4).integers(0, 256, shape, dtype=np.uint8)
+    got = cv.blur(x, ks)
+    want = oracle.box_blur(x, ks)
+    assert got.shape == want.shape and np.array_equal(got, want)
+    # the reference's call convention: a border constant in the 3rd slot is ignored
+    assert np.array_equal(cv.blur(x, ks, cv.BORDER_REPLICATE), want)
+
+
 # ---- step 3: morphology ---------------------------------------------------
 
 def _kernels(rng):
