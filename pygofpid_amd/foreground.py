@@ -159,6 +159,30 @@ class ForegroundPipeline:
         return {"weight": wt, "var": var, "mean": mean, "modes": modes,
                 "nframes": _lib.load().gof_mog2_nframes(m)}
 
+    def save_state(self, path):
+        """Checkpoint the background model (the reference never serialises it, SURVEY.md
+        section 5): an .npz of the SoA planes plus the frame counter and geometry."""
+        st = self.mog2_state()
+        np.savez_compressed(path, geometry=np.array([self.streams, self.h, self.w, self.c]), **st)
+
+    def load_state(self, path):
+        """Restore a checkpoint written by save_state() into this pipeline."""
+        with np.load(path, allow_pickle=False) as z:
+            if z["geometry"].tolist() != [self.streams, self.h, self.w, self.c]:
+                raise ValueError("checkpoint geometry %r does not match %r"
+                                 % (z["geometry"].tolist(), [self.streams, self.h, self.w, self.c]))
+            m = _lib.load().gof_pipeline_mog2(self._h)
+            if not m:
+                raise RuntimeError("not a MOG2 pipeline")
+            f32 = C.POINTER(C.c_float)
+            wt = np.ascontiguousarray(z["weight"], np.float32)
+            var = np.ascontiguousarray(z["var"], np.float32)
+            mean = np.ascontiguousarray(z["mean"], np.float32)
+            modes = np.ascontiguousarray(z["modes"], np.uint8)
+            _lib.check(_lib.load().gof_mog2_import(m, wt.ctypes.data_as(f32), var.ctypes.data_as(f32),
+                                                   mean.ctypes.data_as(f32), _lib.p8(modes),
+                                                   int(z["nframes"])))
+
     def mog2_device_state(self):
         """(device pointer, bytes) of the whole model: one buffer, RCCL-broadcastable."""
         m = _lib.load().gof_pipeline_mog2(self._h)

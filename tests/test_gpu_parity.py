@@ -363,6 +363,26 @@ def test_pipeline_temporal_blocking_other_paths(oracle):
                 assert np.array_equal(got[i], ref.apply(frames[i])), (kind, r, i)
 
 
+def test_pipeline_checkpoint_restore(tmp_path):
+    """save_state -> load_state into a fresh pipeline -> identical continuation
+    (fail-over of a long-running stream)."""
+    from pygofpid_amd.foreground import ForegroundPipeline
+    S, h, w, c = 2, 40, 56, 3
+    clips = [Clip(h, w, c, seed=50 + s) for s in range(S)]
+    a = ForegroundPipeline((h, w, c), streams=S)
+    for t in range(0, 24, 8):
+        a.apply_many(np.stack([np.stack([cl.frame(t + i) for cl in clips]) for i in range(8)]))
+    path = str(tmp_path / "model.npz")
+    a.save_state(path)
+    b = ForegroundPipeline((h, w, c), streams=S)
+    b.load_state(path)
+    for t in range(24, 34):
+        f = np.stack([cl.frame(t) for cl in clips])
+        assert np.array_equal(a.apply(f), b.apply(f))
+    with pytest.raises(ValueError):
+        ForegroundPipeline((h, w + 8, c), streams=S).load_state(path)
+
+
 def test_pipeline_full_hd_bit_exact(oracle):
     """BASELINE config 2 geometry, a few frames against the oracle."""
     from pygofpid_amd.foreground import ForegroundPipeline
