@@ -518,8 +518,6 @@ int gof_mog2_create(gof_ctx *ctx, int streams, int h, int w, int c, const gof_mo
     m->c = c;
     size_t n = (size_t)streams * h * w;
     m->np = (n + 63) & ~(size_t)63;   // planes start on 256-B boundaries
-    if (const char *e = getenv("GOF_PITCH_PAD"))   // tuning knob: extra floats of plane pitch
-        m->np += (size_t)(atoi(e) > 0 ? atoi(e) : 0) & ~(size_t)63;
     m->state_bytes = (size_t)pp.nmixtures * (2 + c) * m->np * sizeof(float) + m->np;
     GOF_HIP(hipSetDevice(ctx->device));
     hipError_t e = hipMalloc(&m->state, m->state_bytes);

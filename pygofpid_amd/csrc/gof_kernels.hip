@@ -1443,10 +1443,7 @@ hipError_t morph_rect_chain(const uint8_t *src, uint8_t *dst, int n_img, int h, 
     const int fast = (w % 4 == 0) && ((uintptr_t)src % 4 == 0) && ((uintptr_t)dst % 4 == 0);
     static const bool no_stream = getenv("GOF_MORPH_LDS") != nullptr;   // A/B knob
     if (!no_stream && stream_geometry(ch, &HQ, &RY)) {
-        int NR = RY <= 4 ? 24 : (RY <= 8 ? 32 : 48);
-        if (const char *e = getenv("GOF_MORPH_NR"))   // tuning knob
-            if (atoi(e) - 2 * RY >= 4)
-                NR = atoi(e);
+        const int NR = RY <= 4 ? 24 : (RY <= 8 ? 32 : 48);   // register rows per strip
         const int rows_out = NR - 2 * RY, strip_px = (64 - 2 * HQ) * 4;
         if ((h + rows_out - 1) / rows_out > 65535)
             return hipErrorInvalidValue;

@@ -184,3 +184,30 @@ def test_gofpid_intrusion_scenario(G):
     canvas = frame.copy()
     gofpid.display(canvas, {'tracking': True, 'perspective': True})
     assert canvas.shape == frame.shape
+
+
+def test_ilids_view_configs_masks_bit_exact(oracle):
+    """BASELINE.json config 5: the reference's i-LIDS view-1 / view-2 configurations
+    (examples/dataset_ilids.py:52-83) on 720x576 synthetic stand-ins, streams
+    sharded round-robin as over 8 GPUs; every foreground mask equals the CPU oracle's."""
+    import importlib.util
+    import os
+    from pygofpid_amd import distributed as gd
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples",
+                        "ilids_synthetic.py")
+    spec = importlib.util.spec_from_file_location("ilids_synthetic", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert len(mod.VIDEO_NAMES) == 33
+    shards = [gd.shard_streams(33, 8, r) for r in range(8)]
+    assert sorted(sum(shards, [])) == list(range(33))
+    for s in shards[3][:2] + shards[7][:1]:            # a few streams of two ranks
+        name = mod.VIDEO_NAMES[s]
+        gofpid = mod.get_gofpid(name[5])
+        ref = oracle.Pipeline(576, 720, 3)
+        clip = Clip(576, 720, 3, seed=100 + s, n_objects=2)
+        for t in range(6):
+            f = clip.frame(t)
+            assert gofpid.detect(f) in (True, False)
+            assert np.array_equal(gofpid.foreground_mask_, ref.apply(f))
+        assert gofpid.post_filter['perimeter'].dtype == np.int32      # calibrated to pixels
