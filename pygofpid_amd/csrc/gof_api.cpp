@@ -849,7 +849,10 @@ int gof_pipeline_create(gof_ctx *ctx, const gof_pipeline_desc *desc, gof_pipelin
         if ((rc = make_taps(desc->blur_kw, desc->blur_kh, desc->blur_sigma_x, desc->blur_sigma_y,
                             &p->taps)))
             return bail(rc);
-        p->fuse_blur3 = desc->detector == GOF_DET_MOG2 && p->taps.nkx == 3 && p->taps.nky == 3;
+        // fused into the MOG2 kernel: 3x3, horizontal taps that fit a byte (a degenerate
+        // sigma gives [0, 256, 0], which goes through the generic blur instead)
+        p->fuse_blur3 = desc->detector == GOF_DET_MOG2 && p->taps.nkx == 3 && p->taps.nky == 3 &&
+                        p->taps.kx[0] < 256 && p->taps.kx[1] < 256 && p->taps.kx[2] < 256;
     } else if (desc->blur == GOF_BLUR_BOX) {
         if ((rc = make_box(desc->blur_kw, desc->blur_kh, &p->taps)))
             return bail(rc);

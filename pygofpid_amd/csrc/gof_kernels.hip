@@ -233,19 +233,6 @@ __device__ __forceinline__ uint8_t mog2_update(PixelModel<C> &M, int &nmodes_io,
     return shadow_test<C, LOUT>(M, nmodes, x, k) ? (uint8_t)k.shadow_value : (uint8_t)255;
 }
 
-typedef unsigned short gof_u16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t pk_mul_u16(uint32_t a, uint32_t b)
-{
-    gof_u16x2 r = __builtin_bit_cast(gof_u16x2, a) * __builtin_bit_cast(gof_u16x2, b);
-    return __builtin_bit_cast(uint32_t, r);
-}
-__device__ __forceinline__ uint32_t pk_mad_u16(uint32_t a, uint32_t b, uint32_t c)
-{
-    gof_u16x2 r = __builtin_bit_cast(gof_u16x2, a) * __builtin_bit_cast(gof_u16x2, b) +
-                  __builtin_bit_cast(gof_u16x2, c);
-    return __builtin_bit_cast(uint32_t, r);
-}
-
 // The MAXIN = 1 instance of mog2_update written without per-lane branches on the
 // common path.  Same statements on the same values (every lane evaluates the fit
 // arithmetic, selects keep it only where the reference would have executed it);
@@ -352,7 +339,10 @@ __device__ __forceinline__ int reflect1(int p, int len)
 // single-frame launches: same statements in the same order on the same values.
 // MULTI = false is the single-frame instance (T == 1 known at compile time: no
 // loop-carried state, 64 VGPRs, 8 waves per SIMD).
-template <int C, bool BLUR3, bool MULTI>
+// ALN = true: every staged frame row starts at the same byte offset mod 4 (row
+// pitch and frame pitch multiples of 4, 4-byte aligned base -- the launcher
+// checks), so the lane's window addresses and byte shifts are loop invariants.
+template <int C, bool BLUR3, bool MULTI, bool ALN>
 __global__ __launch_bounds__(256) void mog2_kernel(const uint8_t *__restrict__ frame,
                                                    uint8_t *__restrict__ mask,
                                                    float *__restrict__ planes,
@@ -471,15 +461,42 @@ __global__ __launch_bounds__(256) void mog2_kernel(const uint8_t *__restrict__ f
         }
     }
 
-    const int kx0 = (int)(kx012 & 1023), kx1 = (int)((kx012 >> 10) & 1023), kx2 = (int)(kx012 >> 20);
+    // the three horizontal taps as bytes (< 256 each, the launcher checks)
+    const uint32_t kxw = (kx012 & 1023u) | (((kx012 >> 10) & 1023u) << 8) | ((kx012 >> 20) << 16);
     const int ky[3] = {(int)(ky012 & 1023), (int)((ky012 >> 10) & 1023), (int)(ky012 >> 20)};
     // byte offsets (within a staged row) of the left / centre / right pixel
     const int xc = valid ? x : sx0;
     const int pl = (reflect1(xc - 1, W) - sx0) * C, pc = (xc - sx0) * C,
               pr = (reflect1(xc + 1, W) - sx0) * C;
 
-    if (BLUR3)
-        __syncthreads();   // the only barrier: all tiles are in LDS
+    // per-frame learning rates (host-computed) parked in LDS: a wave-uniform LDS
+    // read per frame instead of a select chain over the kernel arguments
+    __shared__ float rates_lds[2 * kMaxT];
+    if (MULTI) {
+#pragma unroll
+        for (int q = 0; q < kMaxT; q++) {
+            if (threadIdx.x == (unsigned)q) {
+                rates_lds[q] = k.alphaT_f[q];
+                rates_lds[kMaxT + q] = k.prune_f[q];
+            }
+        }
+    }
+    if (BLUR3 || MULTI)
+        __syncthreads();   // the only barrier: all tiles (and the rates) are in LDS
+
+    // invariant window addressing (ALN): byte address of the dword holding the
+    // left / centre / right pixel in staged row `wave` of frame 0, and the shifts
+    uint32_t aL = 0, aC = 0, aR = 0, sL = 0, sC = 0, sR = 0;
+    if (BLUR3 && ALN) {
+        const int mis0 = (int)((uintptr_t)(frame + ((size_t)img * N * C) + (size_t)sx0 * C) & 3);
+        const uint32_t base = (uint32_t)(wave * ROWD) * 4u;
+        aL = base + (uint32_t)((mis0 + pl) & ~3);
+        aC = base + (uint32_t)((mis0 + pc) & ~3);
+        aR = base + (uint32_t)((mis0 + pr) & ~3);
+        sL = (uint32_t)(mis0 + pl) & 3u;
+        sC = (uint32_t)(mis0 + pc) & 3u;
+        sR = (uint32_t)(mis0 + pr) & 3u;
+    }
 
     // blurred (or raw) pixel of frame ti as floats
     auto frame_input = [&](int ti, float (&xin)[C]) {
@@ -492,33 +509,42 @@ __global__ __launch_bounds__(256) void mog2_kernel(const uint8_t *__restrict__ f
                 acc[c] = 32768u;
 #pragma unroll
             for (int j = 0; j < 3; j++) {
-                const int r = wave + j;
-                const int gy = reflect1(y0 - 1 + r, H);
-                const int gyc = gy < H ? gy : H - 1;
-                const int mis = (int)((uintptr_t)(fimg + ((size_t)gyc * W + sx0) * C) & 3);
-                const uint32_t *row = tile + r * ROWD;
-                // C consecutive bytes starting at byte offset o of the staged row
-                auto px = [&](int o) -> uint32_t {
-                    o += mis;
-                    const uint32_t lo = row[o >> 2], hi = row[(o >> 2) + 1];
-                    return __builtin_amdgcn_alignbyte(hi, lo, (unsigned)(o & 3));
-                };
-                const uint32_t L = px(pl), Cn = px(pc), R = px(pr);
-                // horizontal pass on u16 pairs: the sums are exact in 16 bits
-                // (taps add to 256), two channels per v_pk_mad_u16
-                const uint32_t kk0 = (uint32_t)kx0 * 0x00010001u, kk1 = (uint32_t)kx1 * 0x00010001u,
-                               kk2 = (uint32_t)kx2 * 0x00010001u;
-                auto lo2 = [](uint32_t v) { return __builtin_amdgcn_perm(0u, v, 0x0C010C00u); };   // (b0, b1)
-                auto hi2 = [](uint32_t v) { return __builtin_amdgcn_perm(0u, v, 0x0C030C02u); };   // (b2, b3)
-                uint32_t h01 = pk_mad_u16(lo2(R), kk2, pk_mad_u16(lo2(Cn), kk1, pk_mul_u16(lo2(L), kk0)));
-                acc[0] += ky[j] * (h01 & 0xFFFFu);
-                if (C > 1)
-                    acc[1] += ky[j] * (h01 >> 16);
-                if (C > 2) {
-                    uint32_t h23 = pk_mad_u16(hi2(R), kk2, pk_mad_u16(hi2(Cn), kk1, pk_mul_u16(hi2(L), kk0)));
-                    acc[2] += ky[j] * (h23 & 0xFFFFu);
-                    if (C > 3)
-                        acc[3 % C] += ky[j] * (h23 >> 16);
+                uint32_t L, Cn, R;
+                if (ALN) {
+                    // row j of frame ti: a wave-uniform offset from the lane's frame-0 addresses
+                    const uint32_t off = (uint32_t)(ti * TILE + j * ROWD) * 4u;
+                    auto win = [&](uint32_t a, uint32_t sh) -> uint32_t {
+                        const uint32_t *q = (const uint32_t *)((const char *)tiles + a + off);
+                        return __builtin_amdgcn_alignbyte(q[1], q[0], sh);
+                    };
+                    L = win(aL, sL);
+                    Cn = win(aC, sC);
+                    R = win(aR, sR);
+                } else {
+                    const int r = wave + j;
+                    const int gy = reflect1(y0 - 1 + r, H);
+                    const int gyc = gy < H ? gy : H - 1;
+                    const int mis = (int)((uintptr_t)(fimg + ((size_t)gyc * W + sx0) * C) & 3);
+                    const uint32_t *row = tile + r * ROWD;
+                    // C consecutive bytes starting at byte offset o of the staged row
+                    auto px = [&](int o) -> uint32_t {
+                        o += mis;
+                        const uint32_t lo = row[o >> 2], hi = row[(o >> 2) + 1];
+                        return __builtin_amdgcn_alignbyte(hi, lo, (unsigned)(o & 3));
+                    };
+                    L = px(pl);
+                    Cn = px(pc);
+                    R = px(pr);
+                }
+                // horizontal pass: gather (L_c, C_c, R_c, 0) with two v_perm and take the
+                // dot product with the byte taps (v_dot4_u32_u8); exact, the taps are < 256
+#pragma unroll
+                for (int c = 0; c < C; c++) {
+                    const uint32_t t = __builtin_amdgcn_perm(Cn, L, 0x0C0C0000u | ((4u + c) << 8) | (uint32_t)c);
+                    const uint32_t g = __builtin_amdgcn_perm(R, t, 0x0C000100u | ((4u + c) << 16));
+                    // 24-bit multiply-add: the sums are < 2^16, the taps < 2^9 (full-rate
+                    // v_mad_u32_u24 instead of the quarter-rate 32-bit multiply)
+                    acc[c] = __umul24((uint32_t)ky[j], __builtin_amdgcn_udot4(g, kxw, 0u, false)) + acc[c];
                 }
             }
 #pragma unroll
@@ -531,19 +557,13 @@ __global__ __launch_bounds__(256) void mog2_kernel(const uint8_t *__restrict__ f
                 xin[c] = (float)fp[c];
         }
     };
-    // per-frame learning rate (host-computed, wave-uniform select over ti)
+    // per-frame learning rate (host-computed, one wave-uniform LDS read per frame)
     auto frame_consts = [&](int ti) -> Mog2Consts {
         Mog2Consts kt = k;
         if (MULTI) {
-            float a = k.alphaT_f[0], pr = k.prune_f[0];
-#pragma unroll
-            for (int q = 1; q < kMaxT; q++) {
-                a = ti == q ? k.alphaT_f[q] : a;
-                pr = ti == q ? k.prune_f[q] : pr;
-            }
-            kt.alphaT = a;
-            kt.alpha1 = 1.f - a;
-            kt.prune = pr;
+            kt.alphaT = rates_lds[ti];
+            kt.alpha1 = 1.f - kt.alphaT;
+            kt.prune = rates_lds[kMaxT + ti];
         }
         return kt;
     };
@@ -1315,8 +1335,8 @@ hipError_t mog2_apply(const uint8_t *frame, uint8_t *mask, const Mog2State &st, 
     if (n_img < 1 || h < 1 || w < 1 || (h + TH - 1) / TH > 65535 || n_img > 65535 ||
         st.np < (size_t)n_img * h * w || k.nmix < 1 || k.nmix > kMaxModes || T < 1 || T > kMaxT)
         return hipErrorInvalidValue;
-    if (fused_blur3 && (t.nkx != 3 || t.nky != 3))
-        return hipErrorInvalidValue;
+    if (fused_blur3 && (t.nkx != 3 || t.nky != 3 || t.kx[0] > 255 || t.kx[1] > 255 || t.kx[2] > 255))
+        return hipErrorInvalidValue;   // the fused horizontal pass uses byte taps
     uint32_t kx = 0, ky = 0;
     if (fused_blur3) {
         kx = t.kx[0] | (t.kx[1] << 10) | (t.kx[2] << 20);
@@ -1325,14 +1345,23 @@ hipError_t mog2_apply(const uint8_t *frame, uint8_t *mask, const Mog2State &st, 
     // frames [T][n_img][h][w][c], masks [T][n_img][h][w]
     const size_t fstride = (size_t)n_img * h * w * c, mstride = (size_t)n_img * h * w;
     dim3 g = grid3(w, h, n_img, TW, TH);
+    // invariant window addressing needs every staged row of every frame to start at
+    // the same offset mod 4
+    const bool aln = fused_blur3 && ((size_t)w * c) % 4 == 0 && fstride % 4 == 0 &&
+                     ((size_t)h * w * c) % 4 == 0 && (uintptr_t)frame % 4 == 0;
+#define GOF_LAUNCH_MOG2_(CC, BB, MM, AA)                                                         \
+    hipLaunchKernelGGL((mog2_kernel<CC, BB, MM, AA>), g, dim3(256), 0, s, frame, mask,           \
+                       st.planes, st.modes, st.np, h, w, T, fstride, mstride, k, kx, ky)
 #define GOF_LAUNCH_MOG2(CC, BB)                                                                  \
     do {                                                                                         \
-        if (T == 1)                                                                              \
-            hipLaunchKernelGGL((mog2_kernel<CC, BB, false>), g, dim3(256), 0, s, frame, mask,    \
-                               st.planes, st.modes, st.np, h, w, T, fstride, mstride, k, kx, ky); \
+        if (T == 1 && aln)                                                                       \
+            GOF_LAUNCH_MOG2_(CC, BB, false, (BB));                                               \
+        else if (T == 1)                                                                         \
+            GOF_LAUNCH_MOG2_(CC, BB, false, false);                                              \
+        else if (aln)                                                                            \
+            GOF_LAUNCH_MOG2_(CC, BB, true, (BB));                                                \
         else                                                                                     \
-            hipLaunchKernelGGL((mog2_kernel<CC, BB, true>), g, dim3(256), 0, s, frame, mask,     \
-                               st.planes, st.modes, st.np, h, w, T, fstride, mstride, k, kx, ky); \
+            GOF_LAUNCH_MOG2_(CC, BB, true, false);                                               \
     } while (0)
     if (fused_blur3) {
         switch (c) {
@@ -1350,6 +1379,7 @@ hipError_t mog2_apply(const uint8_t *frame, uint8_t *mask, const Mog2State &st, 
         }
     }
 #undef GOF_LAUNCH_MOG2
+#undef GOF_LAUNCH_MOG2_
     return hipGetLastError();
 }
 

@@ -274,7 +274,7 @@ def test_pipeline_open_close_7x7(oracle):
     _run_pair(gpu, ref, Clip(90, 120, 3, seed=5).frames(25))
 
 
-@pytest.mark.parametrize("blur", [None, (5, 5, 4.0), (3, 3, 0.0)])
+@pytest.mark.parametrize("blur", [None, (5, 5, 4.0), (3, 3, 0.0), (3, 3, 0.05), (3, 3, 1.0)])
 def test_pipeline_other_blurs(oracle, blur):
     from pygofpid_amd.foreground import ForegroundPipeline
     gpu = ForegroundPipeline((50, 70, 3), blur=blur)
