@@ -1035,9 +1035,13 @@ __device__ __forceinline__ void stream_op(uint32_t (&E)[NR], uint32_t (&O)[NR], 
 // dwords: 4 px per instruction, no even/odd split.  Every mask a detector of
 // this library produces is such a chain: MOG2 {0, shadow_value, 255} (0 and 255
 // are below / above every byte), FD {0, 255}, {0, 84, 85} (BGR) or {0, 63} (4 ch).
-template <int NR, bool IS_MAX, int RY>
-__device__ __forceinline__ void stream_op_bits(uint32_t (&R)[NR], int rx)
+// RXT >= 0: the horizontal radius is a compile-time constant (square kernels, the
+// common case) so that only the taps that exist are emitted; RXT = -1 takes it at
+// run time (hipcc then predicates all four tap levels instead of branching).
+template <int NR, bool IS_MAX, int RY, int RXT>
+__device__ __forceinline__ void stream_op_bits(uint32_t (&R)[NR], int rx_rt)
 {
+    const int rx = RXT >= 0 ? RXT : rx_rt;
 #pragma unroll
     for (int j = 0; j < NR; j++) {
         const uint32_t r = R[j];
@@ -1118,17 +1122,27 @@ __global__ __launch_bounds__(64) void morph_stream_bits_kernel(const uint8_t *__
     for (int o = 0; o < ch.n; o++) {
         const int rx = ch.rx[o], ry = ch.ry[o];
         const bool mx = ch.op[o] != 0;
-#define GOF_STREAM_OP(RR)                                  \
+#define GOF_STREAM_OP(RR, XX)                              \
     if (mx)                                                \
-        stream_op_bits<NR, true, RR>(R, rx);               \
+        stream_op_bits<NR, true, RR, XX>(R, rx);           \
     else                                                   \
-        stream_op_bits<NR, false, RR>(R, rx);
-        switch (ry) {
-        case 0: GOF_STREAM_OP(0) break;
-        case 1: GOF_STREAM_OP(1) break;
-        case 2: GOF_STREAM_OP(2) break;
-        case 3: GOF_STREAM_OP(3) break;
-        default: GOF_STREAM_OP(4) break;
+        stream_op_bits<NR, false, RR, XX>(R, rx);
+        if (rx == ry) {   // square kernels: both radii static
+            switch (ry) {
+            case 0: GOF_STREAM_OP(0, 0) break;
+            case 1: GOF_STREAM_OP(1, 1) break;
+            case 2: GOF_STREAM_OP(2, 2) break;
+            case 3: GOF_STREAM_OP(3, 3) break;
+            default: GOF_STREAM_OP(4, 4) break;
+            }
+        } else {
+            switch (ry) {
+            case 0: GOF_STREAM_OP(0, -1) break;
+            case 1: GOF_STREAM_OP(1, -1) break;
+            case 2: GOF_STREAM_OP(2, -1) break;
+            case 3: GOF_STREAM_OP(3, -1) break;
+            default: GOF_STREAM_OP(4, -1) break;
+            }
         }
 #undef GOF_STREAM_OP
         ycum += ry;
@@ -1473,7 +1487,7 @@ hipError_t morph_rect_chain(const uint8_t *src, uint8_t *dst, int n_img, int h, 
     const int fast = (w % 4 == 0) && ((uintptr_t)src % 4 == 0) && ((uintptr_t)dst % 4 == 0);
     static const bool no_stream = getenv("GOF_MORPH_LDS") != nullptr;   // A/B knob
     if (!no_stream && stream_geometry(ch, &HQ, &RY)) {
-        const int NR = RY <= 4 ? 24 : (RY <= 8 ? 32 : 48);   // register rows per strip
+        const int NR = RY <= 8 ? 32 : 48;   // register rows per strip (32 measured best for RY = 4)
         const int rows_out = NR - 2 * RY, strip_px = (64 - 2 * HQ) * 4;
         if ((h + rows_out - 1) / rows_out > 65535)
             return hipErrorInvalidValue;
