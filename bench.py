@@ -125,6 +125,8 @@ def main():
                     help="consecutive frames of every stream handed over per step (temporal "
                          "blocking: the MOG2 model crosses HBM once per 8 frames)")
     ap.add_argument("--objects", type=int, default=6, help="moving rectangles per stream")
+    ap.add_argument("--morph", default="erode5,dilate5",
+                    help="mat_morph list, e.g. erode7,dilate7,dilate7,erode7 (BASELINE config 3)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="0 disables the CPU leg")
     ap.add_argument("--traffic-file", default=os.path.join(ROOT, "profiles", "traffic_latest.json"))
     ap.add_argument("--no-events", action="store_true",
@@ -163,7 +165,13 @@ def main():
     torch.cuda.synchronize()
 
     ctx = _lib.Context(dev_index)
-    pipe = ForegroundPipeline((h, w, 3), streams=S, ctx=ctx)
+    import numpy as np
+    morph = []
+    for item in [m for m in args.morph.split(",") if m]:
+        op = "erode" if item.startswith("erode") else "dilate"
+        kk = int(item[len(op):])
+        morph.append((op, np.ones((kk, kk), np.uint8)))
+    pipe = ForegroundPipeline((h, w, 3), streams=S, ctx=ctx, morph=morph)
     P = args.pool
 
     def barrier():
@@ -236,9 +244,10 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "%dx%d BGR uint8, GaussianBlur 3x3 (sigma 4) -> MOG2 (cv2 defaults, "
-                            "shadows on) -> erode 5x5 -> dilate 5x5; %d streams per GPU, %d "
+                            "shadows on) -> %s; %d streams per GPU, %d "
                             "consecutive frame(s) per stream per step; frames resident in HBM"
-                            % (w, h, S, T),
+                            % (w, h, " -> ".join("%s %dx%d" % (o, k.shape[0], k.shape[1]) for o, k in morph)
+                               or "no morphology", S, T),
                 "streams_per_gpu": S, "frames_per_stream_per_step": T,
                 "frames_per_step": S * T * world, "height": h, "width": w,
                 "channels": 3, "mean_modes": round(mbar, 4), "foreground_fraction": round(fg, 5),
