@@ -289,6 +289,21 @@ class Pipeline:
     def mean_modes(self):
         return lib().gofo_pipeline_mean_modes(self._h)
 
+    def export(self):
+        """SoA planes of the MOG2 model (as MOG2.export), or None for FD."""
+        m = lib().gofo_pipeline_mog2(self._h)
+        if not m:
+            return None
+        h, w, c = self.shape
+        n, K = h * w, 5
+        wt = np.empty((K, n), np.float32)
+        var = np.empty((K, n), np.float32)
+        mean = np.empty((K, c, n), np.float32)
+        modes = np.empty(n, np.uint8)
+        lib().gofo_mog2_export(m, wt.ctypes.data_as(_f32p), var.ctypes.data_as(_f32p),
+                               mean.ctypes.data_as(_f32p), _p8(modes))
+        return {"weight": wt, "var": var, "mean": mean, "modes": modes}
+
     def __del__(self):
         if getattr(self, "_h", None):
             lib().gofo_pipeline_destroy(self._h)

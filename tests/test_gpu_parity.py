@@ -337,7 +337,13 @@ def test_pipeline_temporal_blocking(oracle, T):
                 assert np.array_equal(got[i, s], want), (t + i, s)
         t += T
     assert abs(gpu.mean_modes() - np.mean([r.mean_modes() for r in refs])) < 1e-12
-    assert gpu.mog2_state()["nframes"] == t
+    st = gpu.mog2_state()
+    assert st["nframes"] == t
+    n = h * w
+    for s in range(S):     # per-stream model state, bit for bit
+        got = {"modes": st["modes"][s * n:(s + 1) * n], "weight": st["weight"][:, s * n:(s + 1) * n],
+               "var": st["var"][:, s * n:(s + 1) * n], "mean": st["mean"][:, :, s * n:(s + 1) * n]}
+        _assert_state_equal(got, refs[s].export())
 
 
 def test_pipeline_temporal_blocking_other_paths(oracle):
@@ -361,6 +367,31 @@ def test_pipeline_temporal_blocking_other_paths(oracle):
             got = gpu.apply_many(frames)
             for i in range(5):
                 assert np.array_equal(got[i], ref.apply(frames[i])), (kind, r, i)
+
+
+def test_pipeline_long_run_steady_state(oracle):
+    """640 frames: past frame 250 the learning rate sits at 1/history, modes
+    created by passing objects decay and are pruned (the `nmodes--` path), the
+    weight sort keeps re-ordering.  Masks every frame and the final model state
+    must still be bit-identical, through 8-frame launches."""
+    from pygofpid_amd.foreground import ForegroundPipeline
+    h, w, c = 36, 64, 3
+    clip = Clip(h, w, c, seed=77, n_objects=3, speed=2)
+    gpu = ForegroundPipeline((h, w, c))
+    ref = oracle.Pipeline(h, w, c)
+    peak = 0
+    for t in range(0, 640, 8):
+        frames = np.stack(clip.frames(8, start=t))
+        got = gpu.apply_many(frames)
+        for i in range(8):
+            assert np.array_equal(got[i], ref.apply(frames[i])), t + i
+        if t % 160 == 0:
+            peak = max(peak, int(gpu.mog2_state()["modes"].max()))
+    st = gpu.mog2_state()
+    assert st["nframes"] == 640 and peak >= 3
+    _assert_state_equal(st, ref.export())
+    # pruning happened: some pixel holds fewer modes now than the peak
+    assert st["modes"].min() < peak
 
 
 def test_pipeline_checkpoint_restore(tmp_path):
