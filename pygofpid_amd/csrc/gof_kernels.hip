@@ -68,6 +68,24 @@ __device__ __forceinline__ void swap_modes(PixelModel<C> &M, int i, bool doit)
     }
 }
 
+// IEEE-correct a / b for operands in the normal range with a normal quotient:
+// the Newton / residual chain hipcc itself emits for a float division, without
+// its range scaling (v_div_scale, v_div_fmas' scale) and special-case fix-up
+// (v_div_fixup), which are no-ops there.  8 instructions instead of 11; used
+// where the denominator is a mixture weight (1e-4 .. 2) or a weight sum.
+__device__ __forceinline__ float div_normal(float a, float b)
+{
+    const float r0 = __builtin_amdgcn_rcpf(b);
+    const float nb = -b;
+    const float e0 = __builtin_fmaf(nb, r0, 1.0f);
+    const float r1 = __builtin_fmaf(e0, r0, r0);
+    const float q0 = a * r1;
+    const float e1 = __builtin_fmaf(nb, q0, a);
+    const float q1 = __builtin_fmaf(e1, r1, q0);
+    const float e2 = __builtin_fmaf(nb, q1, a);
+    return __builtin_fmaf(e2, r1, q1);
+}
+
 // detectShadowGMM [OPENCV-RECALL] over the first LIM slots, on the model AFTER
 // this frame's update.  Returns true for a shadow pixel.
 template <int C, int LIM>
@@ -165,7 +183,7 @@ __device__ __forceinline__ uint8_t mog2_update(PixelModel<C> &M, int &nmodes_io,
                     fits = true;
                     fit_here = true;
                     weight += k.alphaT;
-                    float kk = k.alphaT / weight;
+                    float kk = div_normal(k.alphaT, weight);   // weight >= 0.95 alphaT: normal range
 #pragma unroll
                     for (int c = 0; c < C; c++)
                         M.mu[m][c] -= kk * d[c];
@@ -195,7 +213,7 @@ __device__ __forceinline__ uint8_t mog2_update(PixelModel<C> &M, int &nmodes_io,
 
     float inv = 0.f;
     if (fabsf(totalWeight) > FLT_EPSILON)
-        inv = 1.f / totalWeight;
+        inv = div_normal(1.f, totalWeight);
 #pragma unroll
     for (int m = 0; m < LIN; m++)
         if (m < nmodes)
@@ -266,7 +284,7 @@ __device__ __forceinline__ uint8_t mog2_update_single(PixelModel<C> &M, int &nmo
     const bool background = has && 0.f < k.TB && dist2 < k.Tb * var;
     const bool fit = has && dist2 < k.Tg * var;
     const float wfit = weight + k.alphaT;
-    const float kk = k.alphaT / wfit;
+    const float kk = div_normal(k.alphaT, wfit);
 #pragma unroll
     for (int c = 0; c < C; c++) {
         const float mnew = M.mu[0][c] - kk * d[c];
@@ -283,7 +301,7 @@ __device__ __forceinline__ uint8_t mog2_update_single(PixelModel<C> &M, int &nmo
     const float total = has ? 0.f + wstore : 0.f;
     float inv = 0.f;
     if (fabsf(total) > FLT_EPSILON)
-        inv = 1.f / total;
+        inv = div_normal(1.f, total);
     {
         const float wn = nmodes > 0 ? wstore * inv : wstore;
         M.w[0] = has ? wn : M.w[0];
