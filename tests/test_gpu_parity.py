@@ -444,3 +444,43 @@ def test_pipeline_errors():
     p = ForegroundPipeline((10, 10, 3))
     with pytest.raises(ValueError):
         p.apply(np.zeros((12, 10, 3), np.uint8))                # tests/test_pipeline.py:31-41
+
+
+def test_c_abi_error_codes():
+    """The C ABI itself: bad arguments come back as GOF_EINVAL with a message, never a crash."""
+    import ctypes as C
+    from pygofpid_amd import _lib
+    lib = _lib.load()
+    ctx = _lib.default_context()
+    buf = np.zeros((8, 8, 3), np.uint8)
+    out = np.zeros((8, 8, 3), np.uint8)
+    p8 = _lib.p8
+    assert lib.gof_gaussian_blur_host(ctx.handle, None, p8(out), 8, 8, 3, 3, 3, 4.0, 0.0) == _lib.EINVAL
+    assert lib.gof_gaussian_blur_host(ctx.handle, p8(buf), p8(out), 0, 8, 3, 3, 3, 4.0, 0.0) == _lib.EINVAL
+    assert lib.gof_gaussian_blur_host(ctx.handle, p8(buf), p8(out), 8, 8, 2, 3, 3, 4.0, 0.0) == _lib.EINVAL
+    assert lib.gof_gaussian_blur_host(ctx.handle, p8(buf), p8(out), 8, 8, 3, 33, 3, 4.0, 0.0) == _lib.EINVAL
+    assert b"ksize" in lib.gof_last_error()
+    assert lib.gof_morph_host(ctx.handle, 7, p8(buf), p8(out), 8, 8, None, 3, 3) == _lib.EINVAL
+    assert lib.gof_morph_host(ctx.handle, 0, p8(buf), p8(out), 8, 8, None, 0, 3) == _lib.EINVAL
+    h = C.c_void_p()
+    assert lib.gof_mog2_create(ctx.handle, 1, 8, 8, 5, None, C.byref(h)) == _lib.EINVAL and not h
+    p = _lib.Mog2Params()
+    lib.gof_mog2_default_params(C.byref(p))
+    p.nmixtures = 6
+    assert lib.gof_mog2_create(ctx.handle, 1, 8, 8, 3, C.byref(p), C.byref(h)) == _lib.EINVAL
+    bad = C.c_void_p()
+    assert lib.gof_create(99, C.byref(bad)) == _lib.EINVAL and not bad
+    # a pipeline: n_frames out of range, NULL buffers
+    from pygofpid_amd.foreground import ForegroundPipeline
+    pipe = ForegroundPipeline((8, 8, 3))
+    assert lib.gof_pipeline_apply_host_many(pipe._h, p8(buf), p8(out), 0) == _lib.EINVAL
+    assert lib.gof_pipeline_apply_host(pipe._h, None, p8(out)) == _lib.EINVAL
+    assert lib.gof_pipeline_apply_dev_many(pipe._h, None, None, 1, None) == _lib.EINVAL
+    # in-place device calls are refused
+    import torch
+    t = torch.zeros(64 * 3, dtype=torch.uint8, device="cuda")
+    assert lib.gof_gaussian_blur_dev(ctx.handle, t.data_ptr(), t.data_ptr(), 1, 8, 8, 3, 3, 3, 4.0, 0.0,
+                                     None) == _lib.EINVAL
+    assert lib.gof_morph_dev(ctx.handle, 0, t.data_ptr(), t.data_ptr(), 1, 8, 8, None, 3, 3,
+                             None) == _lib.EINVAL
+    assert lib.gof_strerror(_lib.EHIP) == b"HIP runtime error"
