@@ -444,7 +444,9 @@ __global__ __launch_bounds__(256) void mog2_kernel(const uint8_t *__restrict__ f
     float *const prow = planes + rowoff;
     PixelModel<C> M;
     int nmodes = valid ? (int)modes[rowoff + xl] : 0;
+    const int nmodes_in = nmodes;
     M.w[0] = prow[xl];
+    const uint32_t w0_in = __float_as_uint(M.w[0]);
     M.var[0] = (prow + np)[xl];
 #pragma unroll
     for (int c = 0; c < C; c++)
@@ -612,18 +614,26 @@ __global__ __launch_bounds__(256) void mog2_kernel(const uint8_t *__restrict__ f
     if (!valid)
         return;
 
+    // Planes whose value did not change for ANY pixel of the wave are not written
+    // back (wave-uniform test, so a store is always a whole 256-B segment): the
+    // weight of a settled single-mode pixel renormalises to exactly 1.0f frame
+    // after frame, and the mode count rarely changes.
+    const bool w0_dirty = __builtin_amdgcn_ballot_w64(nmodes > 0 && __float_as_uint(M.w[0]) != w0_in) != 0;
+    const bool nm_dirty = __builtin_amdgcn_ballot_w64(nmodes != nmodes_in) != 0;
 #pragma unroll
     for (int m = 0; m < kMaxModes; m++) {
         if (m < nmodes) {
             float *pm = prow + (size_t)m * F * np;
-            pm[xl] = M.w[m];
+            if (m > 0 || w0_dirty)
+                pm[xl] = M.w[m];
             (pm + np)[xl] = M.var[m];
 #pragma unroll
             for (int c = 0; c < C; c++)
                 (pm + (size_t)(2 + c) * np)[xl] = M.mu[m][c];
         }
     }
-    modes[rowoff + xl] = (uint8_t)nmodes;
+    if (nm_dirty)
+        modes[rowoff + xl] = (uint8_t)nmodes;
 }
 
 // ---------------------------------------------------------------------------
