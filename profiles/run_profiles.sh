@@ -8,7 +8,8 @@ OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 FPS=${2:-8}   # frames per stream per step (bench.py default 8; 1 = per-frame form)
-ARGS="bench.py --steps $((64*8/FPS/8+8)) --warmup 16 --frames-per-step $FPS --cpu-seconds 0 --no-events"
+# same K / W as the default bench.py run, so that the per-kernel averages are comparable
+ARGS="bench.py --frames-per-step $FPS --cpu-seconds 0 --no-events"
 # 1. per-kernel time
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python3 $ARGS > $OUT/trace.log 2>&1 || echo "trace failed" >> $OUT/trace.log
 # 2-5. PMC passes, one counter group per run (TCC: FETCH_SIZE needs 3 slots, WRITE_SIZE 2)

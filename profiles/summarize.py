@@ -31,6 +31,11 @@ def main(d, fps=8):
         v2 = sorted(v)
         print("%-70s calls %5d  avg %10.1f  med %10.1f  min %10d  max %10d  %5.1f%%"
               % (k, len(v), sum(v) / len(v), v2[len(v) // 2], v2[0], v2[-1], 100.0 * sum(v) / tot))
+    print("== timed region only (the last 256 dispatches = bench.py's K steps) ==")
+    for k, v in dur.items():
+        if ("mog2" in k or "morph" in k) and len(v) >= 256:
+            t = v[-256:]
+            print("%-70s avg %10.1f ns over %d dispatches" % (k, sum(t) / len(t), len(t)))
     # PMC: average per dispatch per kernel
     pmc = defaultdict(lambda: defaultdict(list))
     for sub in sorted(glob.glob(os.path.join(d, "pmc_*"))):
