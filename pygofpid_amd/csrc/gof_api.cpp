@@ -6,7 +6,9 @@
 #include "gofpid_hip.h"
 
 #include <hip/hip_runtime.h>
+#include <float.h>
 #include <math.h>
+#include <cmath>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -201,6 +203,7 @@ gofk::Mog2Consts next_consts(gof_mog2 *m, int T)
     for (int i = 0; i < gofk::kMaxT; i++) {
         k.alphaT_f[i] = 0.f;
         k.prune_f[i] = 0.f;
+        k.fr[i] = gofk::FrameRates{0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 0u, 0u};
     }
     for (int i = 0; i < T; i++) {
         ++m->nframes;
@@ -208,10 +211,34 @@ gofk::Mog2Consts next_consts(gof_mog2 *m, int T)
         const double lr = 1.0 / (double)d;
         k.alphaT_f[i] = (float)lr;
         k.prune_f[i] = (float)(-lr * m->p.ct);
+        // the update of a lone mode of weight 1.0f, statement for statement as
+        // mog2_update_single evaluates it (float arithmetic, no contraction)
+        const float aT = k.alphaT_f[i], pr = k.prune_f[i];
+        const float a1 = 1.f - aT;
+        const float weight1 = a1 * 1.f + pr;
+        const float wfit1 = weight1 + aT;
+        const float tfit = 0.f + wfit1, tmiss = 0.f + weight1;
+        const bool ok = std::isnormal(wfit1) && std::isnormal(weight1) && !(wfit1 < -pr) &&
+                        !(weight1 < -pr) && std::fabs(tfit) > FLT_EPSILON &&
+                        std::fabs(tmiss) > FLT_EPSILON;
+        gofk::FrameRates &f = k.fr[i];
+        f.alphaT = aT;
+        f.alpha1 = a1;
+        f.prune = pr;
+        if (ok) {
+            f.kk1 = aT / wfit1;
+            f.wnfit = wfit1 * (1.f / tfit);
+            f.wnmiss = weight1 * (1.f / tmiss);
+            f.uni_ok = 1u;
+        }
     }
     k.alphaT = k.alphaT_f[0];
     k.alpha1 = 1.f - k.alphaT;
     k.prune = k.prune_f[0];
+    k.kk1 = k.fr[0].kk1;
+    k.wnfit = k.fr[0].wnfit;
+    k.wnmiss = k.fr[0].wnmiss;
+    k.uni_ok = k.fr[0].uni_ok;
     k.Tb = m->p.var_threshold;
     k.TB = m->p.background_ratio;
     k.Tg = m->p.var_threshold_gen;

@@ -10,15 +10,37 @@ namespace gofk {
 constexpr int kMaxModes = 5;
 constexpr int kMaxKsize = 31;
 
+// Scalars of one frame of a multi-frame launch: one 32-byte record, fetched by
+// the kernel with a single scalar load from its argument segment.
+//   alphaT / alpha1 / prune: the learning-rate terms (alpha1 = 1.f - alphaT).
+//   kk1 / wnfit / wnmiss: the same frame's weight arithmetic for a pixel whose
+//   only mode has weight exactly 1.0f (the settled state: a fitted lone mode
+//   renormalises to 1.0f), evaluated on the host with the kernel's own float
+//   statements.  When every pixel of a wave is in that state the kernel takes
+//   these instead of recomputing a wave-uniform division chain per lane:
+//     weight1 = alpha1 * 1.f + prune; wfit1 = weight1 + alphaT; kk1 = alphaT / wfit1;
+//     wnfit = wfit1 * (1.f / wfit1); wnmiss = weight1 * (1.f / weight1)
+//   uni_ok == 0 switches the shortcut off for this frame (a rate at which the
+//   lone mode would be pruned, or a weight sum not above FLT_EPSILON).
+struct alignas(32) FrameRates {
+    float alphaT, alpha1, prune;
+    float kk1, wnfit, wnmiss;
+    uint32_t uni_ok, pad_;
+};
+
 // Per-frame MOG2 scalars (cv2 BackgroundSubtractorMOG2Impl::apply computes the
 // rates on the host once per frame; restated in gof_api.cpp).
 struct Mog2Consts {
+    FrameRates fr[8];   // the (up to kMaxT) frames of one launch
     // learning rates of the (up to kMaxT) frames of one launch, computed on the
     // host exactly as cv2 does [BackgroundSubtractorMOG2Impl::apply]:
     //   lr = 1.0 / min(2 n, history) in double; alphaT = float(lr);
     //   prune = float(-lr * ct);  (alpha1 = 1.f - alphaT is formed in the kernel)
     float alphaT_f[8], prune_f[8];
     float alphaT, alpha1, prune;   // scratch: the current frame's values
+    // scratch for the settled-wave shortcut (see FrameRates): the current frame's values
+    float kk1, wnfit, wnmiss;
+    uint32_t uni_ok;
     float Tb, TB, Tg;
     float var_init, var_min, var_max, tau;
     int nmix;

@@ -258,14 +258,13 @@ __device__ __forceinline__ uint8_t mog2_update(PixelModel<C> &M, int &nmodes_io,
 // pixel -- sit behind wave-uniform branches.  On a wave of pure background this
 // is a straight line of ~70 vector instructions and no exec-mask bookkeeping,
 // which matters because the multi-frame kernel is bound by VALU + SALU issue.
-template <int C>
+template <int C, bool UNI>
 __device__ __forceinline__ uint8_t mog2_update_single(PixelModel<C> &M, int &nmodes_io,
                                                       const float (&x)[C], const Mog2Consts &k)
 {
     int nmodes = nmodes_io;               // 0 or 1 on entry
     const bool has = nmodes > 0;
     const float var = M.var[0];
-    const float weight = k.alpha1 * M.w[0] + k.prune;
     float d[C];
     float dist2;
     if (C == 3) {
@@ -281,30 +280,48 @@ __device__ __forceinline__ uint8_t mog2_update_single(PixelModel<C> &M, int &nmo
             dist2 += d[c] * d[c];
         }
     }
-    const bool background = has && 0.f < k.TB && dist2 < k.Tb * var;
-    const bool fit = has && dist2 < k.Tg * var;
-    const float wfit = weight + k.alphaT;
-    const float kk = div_normal(k.alphaT, wfit);
+    // mean / variance of a fitted mode 0 (kk = alphaT / weight)
+    auto fit_update = [&](bool fit, float kk) {
 #pragma unroll
-    for (int c = 0; c < C; c++) {
-        const float mnew = M.mu[0][c] - kk * d[c];
-        M.mu[0][c] = fit ? mnew : M.mu[0][c];
-    }
-    float varnew = var + kk * (dist2 - var);
-    varnew = varnew > k.var_min ? varnew : k.var_min;
-    varnew = varnew > k.var_max ? k.var_max : varnew;
-    M.var[0] = fit ? varnew : var;
-    const float w2 = fit ? wfit : weight;
-    const bool pruned = has && w2 < -k.prune;
-    const float wstore = pruned ? 0.f : w2;
-    nmodes -= pruned ? 1 : 0;
-    const float total = has ? 0.f + wstore : 0.f;
-    float inv = 0.f;
-    if (fabsf(total) > FLT_EPSILON)
-        inv = div_normal(1.f, total);
-    {
-        const float wn = nmodes > 0 ? wstore * inv : wstore;
-        M.w[0] = has ? wn : M.w[0];
+        for (int c = 0; c < C; c++) {
+            const float mnew = M.mu[0][c] - kk * d[c];
+            M.mu[0][c] = fit ? mnew : M.mu[0][c];
+        }
+        float varnew = var + kk * (dist2 - var);
+        varnew = varnew > k.var_min ? varnew : k.var_min;
+        varnew = varnew > k.var_max ? k.var_max : varnew;
+        M.var[0] = fit ? varnew : var;
+    };
+    bool background, fit;
+    if (UNI) {
+        // The caller has checked that every pixel of the wave has one mode of
+        // weight exactly 1.0f (where a fitted lone mode renormalises to, frame
+        // after frame).  The weight arithmetic of the else-branch is then the same
+        // for all 64 lanes, and the host has already evaluated it with those
+        // statements (Mog2Consts::kk1 / wnfit / wnmiss).
+        background = 0.f < k.TB && dist2 < k.Tb * var;
+        fit = dist2 < k.Tg * var;
+        fit_update(fit, k.kk1);
+        M.w[0] = fit ? k.wnfit : k.wnmiss;
+    } else {
+        const float weight = k.alpha1 * M.w[0] + k.prune;
+        background = has && 0.f < k.TB && dist2 < k.Tb * var;
+        fit = has && dist2 < k.Tg * var;
+        const float wfit = weight + k.alphaT;
+        const float kk = div_normal(k.alphaT, wfit);
+        fit_update(fit, kk);
+        const float w2 = fit ? wfit : weight;
+        const bool pruned = has && w2 < -k.prune;
+        const float wstore = pruned ? 0.f : w2;
+        nmodes -= pruned ? 1 : 0;
+        const float total = has ? 0.f + wstore : 0.f;
+        float inv = 0.f;
+        if (fabsf(total) > FLT_EPSILON)
+            inv = div_normal(1.f, total);
+        {
+            const float wn = nmodes > 0 ? wstore * inv : wstore;
+            M.w[0] = has ? wn : M.w[0];
+        }
     }
 
     const bool need = !fit && k.alphaT > 0.f;
@@ -601,7 +618,7 @@ __global__ __launch_bounds__(256) void mog2_kernel(const uint8_t *__restrict__ f
         frame_input(ti, xin);
         const Mog2Consts kt = frame_consts(ti);
         if (valid)
-            mask[(size_t)ti * mask_stride + rowoff + xl] = mog2_update_single<C>(M, nmodes, xin, kt);
+            mask[(size_t)ti * mask_stride + rowoff + xl] = mog2_update_single<C, false>(M, nmodes, xin, kt);
     }
     for (; ti < T; ti++) {
         float xin[C];
@@ -634,6 +651,271 @@ __global__ __launch_bounds__(256) void mog2_kernel(const uint8_t *__restrict__ f
     }
     if (nm_dirty)
         modes[rowoff + xl] = (uint8_t)nmodes;
+}
+
+// ---------------------------------------------------------------------------
+// mog2_frames_kernel: the multi-frame launch on aligned frames (what bench.py and
+// ForegroundPipeline.apply_many run).  Same tile, same staging idea and the same
+// update functions as mog2_kernel<C, true, true, true>, re-written around what the
+// counters say bounds that launch: the number of vector AND scalar instructions a
+// wave issues (profiles/ DESIGN.md 5.2), not HBM.
+//   * the frame rows of all T frames are staged from two running row pointers
+//     (every row of every frame has the same offset mod 4, which the launcher
+//     checks): a handful of scalar instructions per frame instead of a 64-bit
+//     address computation per row and frame;
+//   * the per-frame rates come as one 32-byte record from the kernel-argument
+//     segment (one scalar load per frame);
+//   * lanes outside the image shadow a pixel inside it (same model, same
+//     window) and only their stores are masked, so the frame loop runs without
+//     exec-mask bookkeeping;
+//   * settled waves (every pixel one mode of weight exactly 1.0f) take the
+//     host-evaluated weight arithmetic (FrameRates) instead of two division
+//     chains per lane.
+// ---------------------------------------------------------------------------
+struct Mog2FramesArgs {
+    const uint8_t *frame;
+    uint8_t *mask;
+    float *planes;
+    uint8_t *modes;
+    size_t np, frame_stride, mask_stride;
+    int H, W, T;
+    uint32_t kxw;     // horizontal taps as bytes (k0 | k1 << 8 | k2 << 16)
+    uint32_t ky012;   // vertical taps, 10 bits each
+    Mog2Consts k;
+};
+
+template <int C>
+__global__ __launch_bounds__(256) void mog2_frames_kernel(const Mog2FramesArgs a)
+{
+    constexpr int F = 2 + C;
+    constexpr int NDW = (((TW + 2) * C + 3 + 3) / 4 + 1 + 63) / 64;   // dwords per lane and staged row
+    constexpr int ROWD = NDW * 64;   // LDS row pitch in dwords: every lane writes, no predicate
+    constexpr int TILE = (TH + 2) * ROWD;
+    __shared__ uint32_t tiles[kMaxT * TILE];
+
+    const int H = a.H, W = a.W, T = a.T;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    const int img = blockIdx.z;
+    const int x = x0 + lane, y = y0 + wave;
+    const size_t N = (size_t)H * W;
+
+    // ---- stage the (TH+2) x (TW+2) px tiles of all T frames: raw bytes, aligned
+    //      dword loads, rows {wave, wave+4}; borders are resolved at read time ----
+    const int sx0 = x0 > 0 ? x0 - 1 : 0;
+    const int sx1 = (x0 + TW + 1) < W ? (x0 + TW + 1) : W;
+    const int nb = (sx1 - sx0) * C;
+    const uint8_t *img0 = a.frame + (size_t)img * N * C;
+    const int mis0 = (int)((uintptr_t)(img0 + (size_t)sx0 * C) & 3);   // of every staged row
+    const int ndw = (mis0 + nb + 3) >> 2;
+    typedef const uint8_t __attribute__((address_space(1))) *GlobalBytes;
+    GlobalBytes rowp[2];
+#pragma unroll
+    for (int rr = 0; rr < 2; rr++) {
+        const int r = wave + 4 * rr;
+        const int gy = reflect1(y0 - 1 + (r < TH + 2 ? r : 0), H);
+        const int gyc = gy < H ? gy : H - 1;   // rows below a ragged last tile
+        rowp[rr] = (GlobalBytes)(img0 + ((size_t)gyc * W + sx0) * C - mis0);
+    }
+    // straight-line: frames past T re-read frame T-1 (the pointers stop advancing),
+    // so the 2 * kMaxT loads need no branch and share one lane offset
+    uint32_t raw[kMaxT][2][NDW];
+#pragma unroll
+    for (int ti = 0; ti < kMaxT; ti++) {
+        const size_t step = ti + 1 < T ? a.frame_stride : 0;
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++) {
+#pragma unroll
+            for (int q = 0; q < NDW; q++) {
+                // lanes past the row's last dword re-read it (never selected later)
+                const unsigned d = lane + 64 * q < ndw ? lane + 64 * q : ndw - 1;
+                raw[ti][rr][q] = *(const uint32_t __attribute__((address_space(1))) *)(rowp[rr] + d * 4u);   // SGPR base + 32-bit lane offset
+            }
+            rowp[rr] += step;
+        }
+    }
+
+    // ---- model: mode count + mode 0 speculatively, the rest only if present ----
+    const bool valid = y < H && x < W;
+    const int yy = y < H ? y : 0;
+    const unsigned xl = valid ? (unsigned)x : 0u;
+    const size_t rowoff = (size_t)img * N + (size_t)yy * W;   // wave-uniform
+    float *const prow = a.planes + rowoff;
+    const size_t np = a.np;
+    PixelModel<C> M;
+    int nmodes = (int)a.modes[rowoff + xl];
+    const int nmodes_in = nmodes;
+    M.w[0] = prow[xl];
+    const uint32_t w0_in = __float_as_uint(M.w[0]);
+    M.var[0] = (prow + np)[xl];
+#pragma unroll
+    for (int c = 0; c < C; c++)
+        M.mu[0][c] = (prow + (size_t)(2 + c) * np)[xl];
+    if (__builtin_amdgcn_ballot_w64(nmodes > 1) != 0) {
+#pragma unroll
+        for (int m = 1; m < kMaxModes; m++) {
+            if (m < nmodes) {
+                const float *pm = prow + (size_t)m * F * np;
+                M.w[m] = pm[xl];
+                M.var[m] = (pm + np)[xl];
+#pragma unroll
+                for (int c = 0; c < C; c++)
+                    M.mu[m][c] = (pm + (size_t)(2 + c) * np)[xl];
+            } else {
+                M.w[m] = 0.f;
+                M.var[m] = 0.f;
+#pragma unroll
+                for (int c = 0; c < C; c++)
+                    M.mu[m][c] = 0.f;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int m = 1; m < kMaxModes; m++) {
+            M.w[m] = 0.f;
+            M.var[m] = 0.f;
+#pragma unroll
+            for (int c = 0; c < C; c++)
+                M.mu[m][c] = 0.f;
+        }
+    }
+
+    // tiles to LDS (after the model loads are in flight)
+#pragma unroll
+    for (int ti = 0; ti < kMaxT; ti++) {
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++) {
+            const int r = wave + 4 * rr;
+            if (r < TH + 2) {
+#pragma unroll
+                for (int q = 0; q < NDW; q++)
+                    tiles[ti * TILE + r * ROWD + lane + 64 * q] = raw[ti][rr][q];
+            }
+        }
+    }
+
+    // lane-invariant window addressing: byte address (in `tiles`) of the dword that
+    // holds the left / centre / right pixel in staged row `wave` of frame 0, and the
+    // byte shifts; a lane outside the image shadows the tile's first pixel
+    const int xc = valid ? x : x0;
+    const int pl = (reflect1(xc - 1, W) - sx0) * C + mis0, pc = (xc - sx0) * C + mis0,
+              pr = (reflect1(xc + 1, W) - sx0) * C + mis0;
+    const uint32_t rbase = (uint32_t)(wave * ROWD) * 4u;
+    const uint32_t aL = rbase + (uint32_t)(pl & ~3), aC = rbase + (uint32_t)(pc & ~3),
+                   aR = rbase + (uint32_t)(pr & ~3);
+    const uint32_t sL = (uint32_t)pl & 3u, sC = (uint32_t)pc & 3u, sR = (uint32_t)pr & 3u;
+    const uint32_t kxw = a.kxw;
+    const uint32_t ky[3] = {a.ky012 & 1023u, (a.ky012 >> 10) & 1023u, a.ky012 >> 20};
+
+    __syncthreads();   // the only barrier: every tile is in LDS
+
+    // blurred pixel of frame ti: nine windows in one batch of LDS reads, horizontal
+    // pass as v_dot4_u32_u8 on gathered (L, C, R) bytes, vertical pass in 24 bits,
+    // one rounding -- the statements of mog2_kernel's fused front end
+    auto frame_input = [&](int ti, float (&xin)[C]) {
+        uint64_t win[9];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const uint32_t off = (uint32_t)(ti * TILE + j * ROWD) * 4u;
+            const uint32_t a3[3] = {aL, aC, aR};
+#pragma unroll
+            for (int q3 = 0; q3 < 3; q3++) {
+                const uint32_t *q = (const uint32_t *)((const char *)tiles + a3[q3] + off);
+                win[3 * j + q3] = (uint64_t)q[0] | ((uint64_t)q[1] << 32);
+            }
+        }
+        // keeps all nine live at one point: the reads are issued back to back
+        asm volatile(""
+                     : "+v"(win[0]), "+v"(win[1]), "+v"(win[2]), "+v"(win[3]), "+v"(win[4]),
+                       "+v"(win[5]), "+v"(win[6]), "+v"(win[7]), "+v"(win[8]));
+        uint32_t acc[C];
+#pragma unroll
+        for (int c = 0; c < C; c++)
+            acc[c] = 32768u;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const uint32_t L = __builtin_amdgcn_alignbyte((uint32_t)(win[3 * j] >> 32), (uint32_t)win[3 * j], sL);
+            const uint32_t Cn = __builtin_amdgcn_alignbyte((uint32_t)(win[3 * j + 1] >> 32), (uint32_t)win[3 * j + 1], sC);
+            const uint32_t R = __builtin_amdgcn_alignbyte((uint32_t)(win[3 * j + 2] >> 32), (uint32_t)win[3 * j + 2], sR);
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+                const uint32_t t = __builtin_amdgcn_perm(Cn, L, 0x0C0C0000u | ((4u + c) << 8) | (uint32_t)c);
+                const uint32_t g = __builtin_amdgcn_perm(R, t, 0x0C000100u | ((4u + c) << 16));
+                acc[c] = __umul24(ky[j], __builtin_amdgcn_udot4(g, kxw, 0u, false)) + acc[c];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < C; c++)
+            xin[c] = (float)(acc[c] >> 16);
+    };
+    // the frame's scalars: one 32-byte scalar load from the argument segment
+    typedef const Mog2FramesArgs __attribute__((address_space(4))) *ArgsPtr;
+    const ArgsPtr ap = (ArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    auto frame_consts = [&](int ti) -> Mog2Consts {
+        Mog2Consts kt = a.k;
+        kt.alphaT = ap->k.fr[ti].alphaT;
+        kt.alpha1 = ap->k.fr[ti].alpha1;
+        kt.prune = ap->k.fr[ti].prune;
+        kt.kk1 = ap->k.fr[ti].kk1;
+        kt.wnfit = ap->k.fr[ti].wnfit;
+        kt.wnmiss = ap->k.fr[ti].wnmiss;
+        kt.uni_ok = ap->k.fr[ti].uni_ok;
+        return kt;
+    };
+    uint8_t *mrow = a.mask + rowoff + xl;   // this pixel in the mask of frame 0
+
+    // Three frame loops, entered in this order and never re-entered: settled waves,
+    // then waves whose pixels all have at most one mode, then the general update.
+    int ti = 0;
+    for (; ti < T; ti++) {
+        const Mog2Consts kt = frame_consts(ti);
+        float xin[C];
+        frame_input(ti, xin);   // before the test: its LDS reads overlap the scalar load
+        if (kt.uni_ok == 0 || __builtin_amdgcn_ballot_w64(!(nmodes == 1 && M.w[0] == 1.f)) != 0)
+            break;
+        const uint8_t out = mog2_update_single<C, true>(M, nmodes, xin, kt);
+        if (valid)
+            mrow[(size_t)ti * a.mask_stride] = out;
+    }
+    for (; ti < T; ti++) {
+        if (__builtin_amdgcn_ballot_w64(nmodes > 1) != 0)
+            break;
+        const Mog2Consts kt = frame_consts(ti);
+        float xin[C];
+        frame_input(ti, xin);
+        const uint8_t out = mog2_update_single<C, false>(M, nmodes, xin, kt);
+        if (valid)
+            mrow[(size_t)ti * a.mask_stride] = out;
+    }
+    for (; ti < T; ti++) {
+        const Mog2Consts kt = frame_consts(ti);
+        float xin[C];
+        frame_input(ti, xin);
+        const uint8_t out = mog2_update<C, kMaxModes>(M, nmodes, xin, kt);
+        if (valid)
+            mrow[(size_t)ti * a.mask_stride] = out;
+    }
+    if (!valid)
+        return;
+
+    // planes no pixel of the wave changed are not written back (see mog2_kernel)
+    const bool w0_dirty = __builtin_amdgcn_ballot_w64(nmodes > 0 && __float_as_uint(M.w[0]) != w0_in) != 0;
+    const bool nm_dirty = __builtin_amdgcn_ballot_w64(nmodes != nmodes_in) != 0;
+#pragma unroll
+    for (int m = 0; m < kMaxModes; m++) {
+        if (m < nmodes) {
+            float *pm = prow + (size_t)m * F * np;
+            if (m > 0 || w0_dirty)
+                pm[xl] = M.w[m];
+            (pm + np)[xl] = M.var[m];
+#pragma unroll
+            for (int c = 0; c < C; c++)
+                (pm + (size_t)(2 + c) * np)[xl] = M.mu[m][c];
+        }
+    }
+    if (nm_dirty)
+        a.modes[rowoff + xl] = (uint8_t)nmodes;
 }
 
 // ---------------------------------------------------------------------------
@@ -1391,6 +1673,29 @@ hipError_t mog2_apply(const uint8_t *frame, uint8_t *mask, const Mog2State &st, 
     // the same offset mod 4
     const bool aln = fused_blur3 && ((size_t)w * c) % 4 == 0 && fstride % 4 == 0 &&
                      ((size_t)h * w * c) % 4 == 0 && (uintptr_t)frame % 4 == 0;
+    if (aln && T > 1) {   // the multi-frame launch proper
+        Mog2FramesArgs a;
+        a.frame = frame;
+        a.mask = mask;
+        a.planes = st.planes;
+        a.modes = st.modes;
+        a.np = st.np;
+        a.frame_stride = fstride;
+        a.mask_stride = mstride;
+        a.H = h;
+        a.W = w;
+        a.T = T;
+        a.kxw = (uint32_t)t.kx[0] | ((uint32_t)t.kx[1] << 8) | ((uint32_t)t.kx[2] << 16);
+        a.ky012 = ky;
+        a.k = k;
+        switch (c) {
+        case 1: hipLaunchKernelGGL(mog2_frames_kernel<1>, g, dim3(256), 0, s, a); break;
+        case 3: hipLaunchKernelGGL(mog2_frames_kernel<3>, g, dim3(256), 0, s, a); break;
+        case 4: hipLaunchKernelGGL(mog2_frames_kernel<4>, g, dim3(256), 0, s, a); break;
+        default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
 #define GOF_LAUNCH_MOG2_(CC, BB, MM, AA)                                                         \
     hipLaunchKernelGGL((mog2_kernel<CC, BB, MM, AA>), g, dim3(256), 0, s, frame, mask,           \
                        st.planes, st.modes, st.np, h, w, T, fstride, mstride, k, kx, ky)
@@ -1400,8 +1705,6 @@ hipError_t mog2_apply(const uint8_t *frame, uint8_t *mask, const Mog2State &st, 
             GOF_LAUNCH_MOG2_(CC, BB, false, (BB));                                               \
         else if (T == 1)                                                                         \
             GOF_LAUNCH_MOG2_(CC, BB, false, false);                                              \
-        else if (aln)                                                                            \
-            GOF_LAUNCH_MOG2_(CC, BB, true, (BB));                                                \
         else                                                                                     \
             GOF_LAUNCH_MOG2_(CC, BB, true, false);                                               \
     } while (0)
