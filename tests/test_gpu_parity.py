@@ -346,6 +346,75 @@ def test_pipeline_temporal_blocking(oracle, T):
         _assert_state_equal(got, refs[s].export())
 
 
+@pytest.mark.parametrize("shape", [(46, 76, 3), (37, 128, 3), (30, 68, 1), (22, 66, 4), (5, 4, 3)])
+def test_multi_frame_kernel_geometries(oracle, shape):
+    """The dedicated 8-frame kernel (aligned rows: w*c % 4 == 0) on ragged tiles:
+    widths that are not a multiple of the 64-px tile, heights that are not a
+    multiple of 4 (lanes outside the image shadow a pixel inside it), 1 / 3 / 4
+    channels, full and partial launches.  Masks of every frame and the final model
+    state against the frame-by-frame oracle; the scene is quiet enough that whole
+    waves sit in the settled state (one mode of weight exactly 1.0f), which is the
+    path that takes the host-evaluated weight arithmetic."""
+    from pygofpid_amd.foreground import ForegroundPipeline
+    h, w, c = shape
+    S = 2
+    clips = [Clip(h, w, c, seed=300 + s, n_objects=1) for s in range(S)]
+    gpu = ForegroundPipeline((h, w, c), streams=S)
+    refs = [oracle.Pipeline(h, w, c) for _ in range(S)]
+    t = 0
+    for T in (8, 8, 5, 8, 2, 8):
+        frames = np.stack([np.stack([cl.frame(t + i) for cl in clips]) for i in range(T)])
+        got = gpu.apply_many(frames).reshape(T, S, h, w)
+        for i in range(T):
+            for s in range(S):
+                want = refs[s].apply(frames[i, s])
+                assert np.array_equal(got[i, s], want), (shape, t + i, s)
+        t += T
+    st = gpu.mog2_state()
+    n = h * w
+    for s in range(S):
+        got = {"modes": st["modes"][s * n:(s + 1) * n], "weight": st["weight"][:, s * n:(s + 1) * n],
+               "var": st["var"][:, s * n:(s + 1) * n], "mean": st["mean"][:, :, s * n:(s + 1) * n]}
+        _assert_state_equal(got, refs[s].export())
+    settled = (st["modes"] == 1) & (st["weight"][0] == np.float32(1.0))
+    if h * w > 1000:      # (the 5 x 4 image is mostly covered by its moving object)
+        assert settled.mean() > 0.3, settled.mean()
+
+
+@pytest.mark.parametrize("over", [dict(history=6, ct=8.0), dict(history=40, ct=0.0),
+                                  dict(history=3, background_ratio=0.0, var_threshold_gen=30.0),
+                                  dict(nmixtures=1, history=10), dict(nmixtures=2, detect_shadows=0)])
+def test_multi_frame_kernel_other_rates(oracle, over):
+    """Learning-rate terms away from the defaults, through 8-frame launches: rates at
+    which a lone mode of weight 1 would be pruned (the shortcut must switch itself
+    off for those frames), a zero complexity-reduction term, background ratio 0, a
+    single-mode mixture.  Oracle: its own blur -> MOG2 -> erode -> dilate."""
+    from pygofpid_amd import _lib
+    from pygofpid_amd.foreground import ForegroundPipeline
+    import ctypes as C
+    h, w, c = 33, 72, 3
+    p = _lib.Mog2Params()
+    _lib.load().gof_mog2_default_params(C.byref(p))
+    for k, v in over.items():
+        setattr(p, k, v)
+    gpu = ForegroundPipeline((h, w, c), mog2_params=p)
+    ref = oracle.MOG2(**over)
+    k5 = np.ones((5, 5), np.uint8)
+    clip = Clip(h, w, c, seed=91, n_objects=2)
+    for r in range(5):
+        frames = np.stack(clip.frames(8, start=8 * r))
+        got = gpu.apply_many(frames)
+        for i in range(8):
+            want = oracle.dilate(oracle.erode(ref.apply(oracle.gaussian_blur(frames[i])), k5), k5)
+            assert np.array_equal(got[i], want), (over, 8 * r + i)
+    want = ref.export()
+    K = want["weight"].shape[0]       # the oracle exports nmixtures slots, the library always 5
+    pad = lambda a: np.concatenate([a, np.zeros((5 - K,) + a.shape[1:], a.dtype)])
+    want = {"modes": want["modes"], "weight": pad(want["weight"]), "var": pad(want["var"]),
+            "mean": pad(want["mean"])}
+    _assert_state_equal(gpu.mog2_state(), want)
+
+
 def test_pipeline_temporal_blocking_other_paths(oracle):
     """apply_many through the unfused blur, the FD detector and a grey stream."""
     from pygofpid_amd.foreground import ForegroundPipeline
