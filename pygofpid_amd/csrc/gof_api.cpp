@@ -200,6 +200,7 @@ hipStream_t pick(gof_ctx *ctx, void *stream) { return stream ? (hipStream_t)stre
 gofk::Mog2Consts next_consts(gof_mog2 *m, int T)
 {
     gofk::Mog2Consts k;
+    k.uni_mask = 0u;
     for (int i = 0; i < gofk::kMaxT; i++) {
         k.alphaT_f[i] = 0.f;
         k.prune_f[i] = 0.f;
@@ -218,7 +219,7 @@ gofk::Mog2Consts next_consts(gof_mog2 *m, int T)
         const float weight1 = a1 * 1.f + pr;
         const float wfit1 = weight1 + aT;
         const float tfit = 0.f + wfit1, tmiss = 0.f + weight1;
-        const bool ok = std::isnormal(wfit1) && std::isnormal(weight1) && !(wfit1 < -pr) &&
+        const bool ok = m->p.var_min <= m->p.var_max && std::isnormal(wfit1) && std::isnormal(weight1) && !(wfit1 < -pr) &&
                         !(weight1 < -pr) && std::fabs(tfit) > FLT_EPSILON &&
                         std::fabs(tmiss) > FLT_EPSILON;
         gofk::FrameRates &f = k.fr[i];
@@ -230,6 +231,7 @@ gofk::Mog2Consts next_consts(gof_mog2 *m, int T)
             f.wnfit = wfit1 * (1.f / tfit);
             f.wnmiss = weight1 * (1.f / tmiss);
             f.uni_ok = 1u;
+            k.uni_mask |= 1u << i;
         }
     }
     k.alphaT = k.alphaT_f[0];

@@ -32,6 +32,7 @@ struct alignas(32) FrameRates {
 // rates on the host once per frame; restated in gof_api.cpp).
 struct Mog2Consts {
     FrameRates fr[8];   // the (up to kMaxT) frames of one launch
+    uint32_t uni_mask;  // bit i: fr[i].uni_ok
     // learning rates of the (up to kMaxT) frames of one launch, computed on the
     // host exactly as cv2 does [BackgroundSubtractorMOG2Impl::apply]:
     //   lr = 1.0 / min(2 n, history) in double; alphaT = float(lr);

@@ -258,7 +258,7 @@ __device__ __forceinline__ uint8_t mog2_update(PixelModel<C> &M, int &nmodes_io,
 // pixel -- sit behind wave-uniform branches.  On a wave of pure background this
 // is a straight line of ~70 vector instructions and no exec-mask bookkeeping,
 // which matters because the multi-frame kernel is bound by VALU + SALU issue.
-template <int C, bool UNI>
+template <int C>
 __device__ __forceinline__ uint8_t mog2_update_single(PixelModel<C> &M, int &nmodes_io,
                                                       const float (&x)[C], const Mog2Consts &k)
 {
@@ -293,17 +293,7 @@ __device__ __forceinline__ uint8_t mog2_update_single(PixelModel<C> &M, int &nmo
         M.var[0] = fit ? varnew : var;
     };
     bool background, fit;
-    if (UNI) {
-        // The caller has checked that every pixel of the wave has one mode of
-        // weight exactly 1.0f (where a fitted lone mode renormalises to, frame
-        // after frame).  The weight arithmetic of the else-branch is then the same
-        // for all 64 lanes, and the host has already evaluated it with those
-        // statements (Mog2Consts::kk1 / wnfit / wnmiss).
-        background = 0.f < k.TB && dist2 < k.Tb * var;
-        fit = dist2 < k.Tg * var;
-        fit_update(fit, k.kk1);
-        M.w[0] = fit ? k.wnfit : k.wnmiss;
-    } else {
+    {
         const float weight = k.alpha1 * M.w[0] + k.prune;
         background = has && 0.f < k.TB && dist2 < k.Tb * var;
         fit = has && dist2 < k.Tg * var;
@@ -353,6 +343,58 @@ __device__ __forceinline__ uint8_t mog2_update_single(PixelModel<C> &M, int &nmo
             out = shadow_test<C, 2>(M, nmodes, x, k) ? (uint8_t)k.shadow_value : (uint8_t)255;
     }
     return out;
+}
+
+// One frame of a SETTLED wave.  The caller guarantees that every pixel of the wave
+// has exactly one mode and that its weight is exactly 1.0f (where a fitted lone
+// mode renormalises to, frame after frame).  The weight arithmetic of
+// mog2_update_single is then the same for all 64 lanes and the host has already
+// evaluated it with those very statements (FrameRates: kk1 = alphaT / wfit, wnfit =
+// the renormalised weight of the fitted mode).  If, in addition, every pixel fits
+// its mode and is background (the overwhelmingly common frame), what is left per
+// lane is the distance and the mean / variance update: the function commits that
+// and returns true -- every mask byte of the wave is 0.  Otherwise it changes
+// nothing and returns false; the caller redoes the frame with mog2_update_single.
+// `stay`: the wave is still settled after a committed frame.
+template <int C>
+__device__ __forceinline__ bool mog2_try_settled(PixelModel<C> &M, const float (&x)[C],
+                                                 const Mog2Consts &k, bool &stay)
+{
+    constexpr uint32_t kOne = 0x3f800000u;
+    const float var = M.var[0];
+    float d[C];
+    float dist2;
+    if (C == 3) {
+        d[0] = M.mu[0][0] - x[0];
+        d[1] = M.mu[0][1] - x[1];
+        d[2] = M.mu[0][2] - x[2];
+        dist2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+    } else {
+        dist2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            d[c] = M.mu[0][c] - x[c];
+            dist2 += d[c] * d[c];
+        }
+    }
+    const bool fit = dist2 < k.Tg * var;
+    const bool close = dist2 < k.Tb * var;
+    const uint64_t all = __builtin_amdgcn_ballot_w64(true);
+    // 0.f < TB on the scalar unit (a parameter, never NaN)
+    if (__float_as_int(k.TB) <= 0 || __builtin_amdgcn_ballot_w64(fit) != all ||
+        __builtin_amdgcn_ballot_w64(close) != all)
+        return false;
+#pragma unroll
+    for (int c = 0; c < C; c++)
+        M.mu[0][c] = M.mu[0][c] - k.kk1 * d[c];
+    // median of (v, var_min, var_max) instead of two compare + select pairs: the
+    // same value for every v, NaN included, given var_min <= var_max (which the host
+    // checks before it allows this path)
+    M.var[0] = __builtin_amdgcn_fmed3f(var + k.kk1 * (dist2 - var), k.var_min, k.var_max);
+    stay = __float_as_uint(k.wnfit) == kOne;
+    if (!stay)
+        M.w[0] = k.wnfit;
+    return true;
 }
 
 // REFLECT_101 for a reach of one pixel: -1 -> 1, len -> len-2 (len == 1 -> 0)
@@ -618,7 +660,7 @@ __global__ __launch_bounds__(256) void mog2_kernel(const uint8_t *__restrict__ f
         frame_input(ti, xin);
         const Mog2Consts kt = frame_consts(ti);
         if (valid)
-            mask[(size_t)ti * mask_stride + rowoff + xl] = mog2_update_single<C, false>(M, nmodes, xin, kt);
+            mask[(size_t)ti * mask_stride + rowoff + xl] = mog2_update_single<C>(M, nmodes, xin, kt);
     }
     for (; ti < T; ti++) {
         float xin[C];
@@ -752,7 +794,11 @@ __global__ __launch_bounds__(256) void mog2_frames_kernel(const Mog2FramesArgs a
 #pragma unroll
     for (int c = 0; c < C; c++)
         M.mu[0][c] = (prow + (size_t)(2 + c) * np)[xl];
-    if (__builtin_amdgcn_ballot_w64(nmodes > 1) != 0) {
+    // slots 1.. are loaded only if some pixel of the wave has them; otherwise slot 1
+    // starts empty (the single-mode loops may fill it) and slots 2.. stay untouched
+    // until the general loop is entered
+    const bool multi_in = __builtin_amdgcn_ballot_w64(nmodes > 1) != 0;
+    if (multi_in) {
 #pragma unroll
         for (int m = 1; m < kMaxModes; m++) {
             if (m < nmodes) {
@@ -771,14 +817,11 @@ __global__ __launch_bounds__(256) void mog2_frames_kernel(const Mog2FramesArgs a
             }
         }
     } else {
+        M.w[1] = 0.f;
+        M.var[1] = 0.f;
 #pragma unroll
-        for (int m = 1; m < kMaxModes; m++) {
-            M.w[m] = 0.f;
-            M.var[m] = 0.f;
-#pragma unroll
-            for (int c = 0; c < C; c++)
-                M.mu[m][c] = 0.f;
-        }
+        for (int c = 0; c < C; c++)
+            M.mu[1][c] = 0.f;
     }
 
     // tiles to LDS (after the model loads are in flight)
@@ -813,20 +856,24 @@ __global__ __launch_bounds__(256) void mog2_frames_kernel(const Mog2FramesArgs a
     // blurred pixel of frame ti: nine windows in one batch of LDS reads, horizontal
     // pass as v_dot4_u32_u8 on gathered (L, C, R) bytes, vertical pass in 24 bits,
     // one rounding -- the statements of mog2_kernel's fused front end
-    auto frame_input = [&](int ti, float (&xin)[C]) {
+    uint32_t wa[3] = {aL, aC, aR};   // the three window addresses in the current frame's tile
+    auto frame_input = [&](float (&xin)[C], bool batch) {
         uint64_t win[9];
 #pragma unroll
         for (int j = 0; j < 3; j++) {
-            const uint32_t off = (uint32_t)(ti * TILE + j * ROWD) * 4u;
-            const uint32_t a3[3] = {aL, aC, aR};
 #pragma unroll
             for (int q3 = 0; q3 < 3; q3++) {
-                const uint32_t *q = (const uint32_t *)((const char *)tiles + a3[q3] + off);
+                const uint32_t *q = (const uint32_t *)((const char *)tiles + wa[q3] + (uint32_t)(j * ROWD) * 4u);
                 win[3 * j + q3] = (uint64_t)q[0] | ((uint64_t)q[1] << 32);
             }
         }
-        // keeps all nine live at one point: the reads are issued back to back
-        asm volatile(""
+#pragma unroll
+        for (int q3 = 0; q3 < 3; q3++)
+            wa[q3] += (uint32_t)TILE * 4u;   // next frame
+        // keeps all nine live at one point: the reads are issued back to back (not in
+        // the general loop, which has the whole mixture in registers)
+        if (batch)
+            asm volatile(""
                      : "+v"(win[0]), "+v"(win[1]), "+v"(win[2]), "+v"(win[3]), "+v"(win[4]),
                        "+v"(win[5]), "+v"(win[6]), "+v"(win[7]), "+v"(win[8]));
         uint32_t acc[C];
@@ -852,49 +899,87 @@ __global__ __launch_bounds__(256) void mog2_frames_kernel(const Mog2FramesArgs a
     // the frame's scalars: one 32-byte scalar load from the argument segment
     typedef const Mog2FramesArgs __attribute__((address_space(4))) *ArgsPtr;
     const ArgsPtr ap = (ArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
-    auto frame_consts = [&](int ti) -> Mog2Consts {
+    // The frame's scalars: one 32-byte scalar load from the argument segment,
+    // requested one frame ahead (the record of frame ti + 1 travels while frame ti
+    // is computed; a load placed in the iteration that uses it gets sunk to its
+    // first use and its latency lands on the critical path).
+    typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+    auto load_rates = [&](int ti) -> u32x8 {
+        const int tc = ti < kMaxT ? ti : kMaxT - 1;
+        return *(const u32x8 __attribute__((address_space(4))) *)&ap->k.fr[tc];
+    };
+    auto frame_consts = [&](const u32x8 &r) -> Mog2Consts {
         Mog2Consts kt = a.k;
-        kt.alphaT = ap->k.fr[ti].alphaT;
-        kt.alpha1 = ap->k.fr[ti].alpha1;
-        kt.prune = ap->k.fr[ti].prune;
-        kt.kk1 = ap->k.fr[ti].kk1;
-        kt.wnfit = ap->k.fr[ti].wnfit;
-        kt.wnmiss = ap->k.fr[ti].wnmiss;
-        kt.uni_ok = ap->k.fr[ti].uni_ok;
+        kt.alphaT = __uint_as_float(r[0]);
+        kt.alpha1 = __uint_as_float(r[1]);
+        kt.prune = __uint_as_float(r[2]);
+        kt.kk1 = __uint_as_float(r[3]);
+        kt.wnfit = __uint_as_float(r[4]);
+        kt.wnmiss = __uint_as_float(r[5]);
+        kt.uni_ok = r[6];
         return kt;
     };
-    uint8_t *mrow = a.mask + rowoff + xl;   // this pixel in the mask of frame 0
+    uint8_t *mp = a.mask + rowoff + xl;   // this pixel in the mask of the current frame
 
     // Three frame loops, entered in this order and never re-entered: settled waves,
     // then waves whose pixels all have at most one mode, then the general update.
     int ti = 0;
-    for (; ti < T; ti++) {
-        const Mog2Consts kt = frame_consts(ti);
+    u32x8 rates = load_rates(0);
+    // settled on entry?  Afterwards mog2_try_settled reports it frame by frame.
+    bool settled = __builtin_amdgcn_ballot_w64(!(nmodes == 1 && M.w[0] == 1.f)) == 0;
+    // (a.k.uni_mask: the frames whose rates allow the shortcut, known before the
+    // frame's record arrives)
+    while (settled && ti < T && ((a.k.uni_mask >> ti) & 1u) != 0) {
+        const u32x8 next = load_rates(ti + 1);
+        const Mog2Consts kt = frame_consts(rates);
         float xin[C];
-        frame_input(ti, xin);   // before the test: its LDS reads overlap the scalar load
-        if (kt.uni_ok == 0 || __builtin_amdgcn_ballot_w64(!(nmodes == 1 && M.w[0] == 1.f)) != 0)
+        frame_input(xin, true);
+        if (!mog2_try_settled<C>(M, xin, kt, settled)) {
+            // some pixel missed its mode or is not background: redo the frame below
+#pragma unroll
+            for (int q3 = 0; q3 < 3; q3++)
+                wa[q3] -= (uint32_t)TILE * 4u;
             break;
-        const uint8_t out = mog2_update_single<C, true>(M, nmodes, xin, kt);
+        }
         if (valid)
-            mrow[(size_t)ti * a.mask_stride] = out;
+            *mp = 0;
+        mp += a.mask_stride;
+        rates = next;
+        ti++;
     }
     for (; ti < T; ti++) {
         if (__builtin_amdgcn_ballot_w64(nmodes > 1) != 0)
             break;
-        const Mog2Consts kt = frame_consts(ti);
+        const u32x8 next = load_rates(ti + 1);
+        const Mog2Consts kt = frame_consts(rates);
         float xin[C];
-        frame_input(ti, xin);
-        const uint8_t out = mog2_update_single<C, false>(M, nmodes, xin, kt);
+        frame_input(xin, true);
+        const uint8_t out = mog2_update_single<C>(M, nmodes, xin, kt);
         if (valid)
-            mrow[(size_t)ti * a.mask_stride] = out;
+            *mp = out;
+        mp += a.mask_stride;
+        rates = next;
+    }
+    if (!multi_in && ti < T) {
+#pragma unroll
+        for (int m = 2; m < kMaxModes; m++) {
+            M.w[m] = 0.f;
+            M.var[m] = 0.f;
+#pragma unroll
+            for (int c = 0; c < C; c++)
+                M.mu[m][c] = 0.f;
+        }
     }
     for (; ti < T; ti++) {
-        const Mog2Consts kt = frame_consts(ti);
+        const u32x8 next = load_rates(ti + 1);
+        const Mog2Consts kt = frame_consts(rates);
         float xin[C];
-        frame_input(ti, xin);
+        frame_input(xin, false);
         const uint8_t out = mog2_update<C, kMaxModes>(M, nmodes, xin, kt);
         if (valid)
-            mrow[(size_t)ti * a.mask_stride] = out;
+            *mp = out;
+        mp += a.mask_stride;
+        rates = next;
     }
     if (!valid)
         return;
