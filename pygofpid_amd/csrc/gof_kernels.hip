@@ -838,71 +838,98 @@ __global__ __launch_bounds__(256) void mog2_frames_kernel(const Mog2FramesArgs a
         }
     }
 
-    // lane-invariant window addressing: byte address (in `tiles`) of the dword that
-    // holds the left / centre / right pixel in staged row `wave` of frame 0, and the
-    // byte shifts; a lane outside the image shadows the tile's first pixel
+    // Lane-invariant blur addressing.  The three pixels a lane needs from a staged
+    // row (left, centre, right; the border reflection can fold left onto right) lie
+    // within 12 bytes of the aligned address A below the leftmost of them.  Instead
+    // of extracting them (alignbyte + byte permutes), the lane carries, per channel,
+    // a 12-byte tap pattern: the horizontal pass of a row is then three
+    // v_dot4_u32_u8 per channel on the three aligned dwords, nothing else.
+    // a lane outside the image shadows the tile's first pixel
     const int xc = valid ? x : x0;
     const int pl = (reflect1(xc - 1, W) - sx0) * C + mis0, pc = (xc - sx0) * C + mis0,
               pr = (reflect1(xc + 1, W) - sx0) * C + mis0;
-    const uint32_t rbase = (uint32_t)(wave * ROWD) * 4u;
-    const uint32_t aL = rbase + (uint32_t)(pl & ~3), aC = rbase + (uint32_t)(pc & ~3),
-                   aR = rbase + (uint32_t)(pr & ~3);
-    const uint32_t sL = (uint32_t)pl & 3u, sC = (uint32_t)pc & 3u, sR = (uint32_t)pr & 3u;
-    const uint32_t kxw = a.kxw;
+    const int pmin = pl < pc ? (pl < pr ? pl : pr) : (pc < pr ? pc : pr);
+    const int A = pmin & ~3;
+    uint32_t pat[C][3];
+    {
+        // channel 0: byte k0 at pl - A, k1 at pc - A, k2 at pr - A (k0 + k2 where the
+        // reflection folds them; the launcher checks that the sum fits a byte),
+        // as a 96-bit number (lo, hi); channel c is that number shifted by c bytes
+        const uint32_t kx[3] = {a.kxw & 255u, (a.kxw >> 8) & 255u, (a.kxw >> 16) & 255u};
+        const int rel[3] = {pl - A, pc - A, pr - A};   // each 0 .. 3 + 2 C
+        uint64_t lo = 0;
+        uint32_t hi = 0;
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+            const uint32_t sh = 8u * (uint32_t)(rel[t] & 7);
+            if (rel[t] < 8)
+                lo += (uint64_t)kx[t] << sh;
+            else
+                hi += kx[t] << sh;
+        }
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const uint64_t l = c ? lo << (8 * c) : lo;
+            const uint32_t h = c ? (hi << (8 * c)) | (uint32_t)(lo >> (64 - 8 * c)) : hi;
+            pat[c][0] = (uint32_t)l;
+            pat[c][1] = (uint32_t)(l >> 32);
+            pat[c][2] = h;
+        }
+    }
+    uint32_t wa = (uint32_t)(wave * ROWD) * 4u + (uint32_t)A;   // window address, current frame
+    uint32_t half = 32768u;
+    asm volatile("" : "+v"(half));   // keep it in a register (not re-materialised per use)
     const uint32_t ky[3] = {a.ky012 & 1023u, (a.ky012 >> 10) & 1023u, a.ky012 >> 20};
 
     __syncthreads();   // the only barrier: every tile is in LDS
 
-    // blurred pixel of frame ti: nine windows in one batch of LDS reads, horizontal
-    // pass as v_dot4_u32_u8 on gathered (L, C, R) bytes, vertical pass in 24 bits,
-    // one rounding -- the statements of mog2_kernel's fused front end
-    uint32_t wa[3] = {aL, aC, aR};   // the three window addresses in the current frame's tile
+    // blurred pixel of the current frame: 3 x 3 aligned dwords from LDS, horizontal
+    // pass as v_dot4_u32_u8 against the lane's tap patterns, vertical pass as 24-bit
+    // multiply-adds onto the rounding constant, >> 16: the same integer as
+    // mog2_kernel's fused front end (sums of the same products, no intermediate
+    // rounding), which is the separable 8.8 blur of blur_kernel
     auto frame_input = [&](float (&xin)[C], bool batch) {
-        uint64_t win[9];
+        uint32_t win[3][3];
 #pragma unroll
         for (int j = 0; j < 3; j++) {
+            const uint32_t *q = (const uint32_t *)((const char *)tiles + wa + (uint32_t)(j * ROWD) * 4u);
 #pragma unroll
-            for (int q3 = 0; q3 < 3; q3++) {
-                const uint32_t *q = (const uint32_t *)((const char *)tiles + wa[q3] + (uint32_t)(j * ROWD) * 4u);
-                win[3 * j + q3] = (uint64_t)q[0] | ((uint64_t)q[1] << 32);
-            }
+            for (int i = 0; i < 3; i++)
+                win[j][i] = q[i];
         }
-#pragma unroll
-        for (int q3 = 0; q3 < 3; q3++)
-            wa[q3] += (uint32_t)TILE * 4u;   // next frame
+        wa += (uint32_t)TILE * 4u;   // next frame
         // keeps all nine live at one point: the reads are issued back to back (not in
         // the general loop, which has the whole mixture in registers)
         if (batch)
             asm volatile(""
-                     : "+v"(win[0]), "+v"(win[1]), "+v"(win[2]), "+v"(win[3]), "+v"(win[4]),
-                       "+v"(win[5]), "+v"(win[6]), "+v"(win[7]), "+v"(win[8]));
-        uint32_t acc[C];
+                         : "+v"(win[0][0]), "+v"(win[0][1]), "+v"(win[0][2]), "+v"(win[1][0]),
+                           "+v"(win[1][1]), "+v"(win[1][2]), "+v"(win[2][0]), "+v"(win[2][1]),
+                           "+v"(win[2][2]));
 #pragma unroll
-        for (int c = 0; c < C; c++)
-            acc[c] = 32768u;
+        for (int c = 0; c < C; c++) {
+            uint32_t acc = half;   // 2^15 in a VGPR: the multiply-add takes one scalar operand
 #pragma unroll
-        for (int j = 0; j < 3; j++) {
-            const uint32_t L = __builtin_amdgcn_alignbyte((uint32_t)(win[3 * j] >> 32), (uint32_t)win[3 * j], sL);
-            const uint32_t Cn = __builtin_amdgcn_alignbyte((uint32_t)(win[3 * j + 1] >> 32), (uint32_t)win[3 * j + 1], sC);
-            const uint32_t R = __builtin_amdgcn_alignbyte((uint32_t)(win[3 * j + 2] >> 32), (uint32_t)win[3 * j + 2], sR);
-#pragma unroll
-            for (int c = 0; c < C; c++) {
-                const uint32_t t = __builtin_amdgcn_perm(Cn, L, 0x0C0C0000u | ((4u + c) << 8) | (uint32_t)c);
-                const uint32_t g = __builtin_amdgcn_perm(R, t, 0x0C000100u | ((4u + c) << 16));
-                acc[c] = __umul24(ky[j], __builtin_amdgcn_udot4(g, kxw, 0u, false)) + acc[c];
+            for (int j = 0; j < 3; j++) {
+                uint32_t h = __builtin_amdgcn_udot4(win[j][0], pat[c][0], 0u, false);
+                h = __builtin_amdgcn_udot4(win[j][1], pat[c][1], h, false);
+                h = __builtin_amdgcn_udot4(win[j][2], pat[c][2], h, false);
+                // acc += ky[j] * h as ONE v_mad_u32_u24 (h < 2^16, ky < 2^10).  The empty
+                // asm pins the running sum: without it the three products are
+                // re-associated into multiply, multiply-add, multiply, three-way add.
+                // (The multiply-add itself must stay compiler-generated: a VALU read of
+                // a v_dot4 result needs wait states that only the compiler inserts.)
+                acc = __umul24(ky[j], h) + acc;
+                asm volatile("" : "+v"(acc));
             }
+            xin[c] = (float)(acc >> 16);
         }
-#pragma unroll
-        for (int c = 0; c < C; c++)
-            xin[c] = (float)(acc[c] >> 16);
     };
-    // the frame's scalars: one 32-byte scalar load from the argument segment
-    typedef const Mog2FramesArgs __attribute__((address_space(4))) *ArgsPtr;
-    const ArgsPtr ap = (ArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
     // The frame's scalars: one 32-byte scalar load from the argument segment,
     // requested one frame ahead (the record of frame ti + 1 travels while frame ti
     // is computed; a load placed in the iteration that uses it gets sunk to its
     // first use and its latency lands on the critical path).
+    typedef const Mog2FramesArgs __attribute__((address_space(4))) *ArgsPtr;
+    const ArgsPtr ap = (ArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
     typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
     auto load_rates = [&](int ti) -> u32x8 {
         const int tc = ti < kMaxT ? ti : kMaxT - 1;
@@ -936,9 +963,7 @@ __global__ __launch_bounds__(256) void mog2_frames_kernel(const Mog2FramesArgs a
         frame_input(xin, true);
         if (!mog2_try_settled<C>(M, xin, kt, settled)) {
             // some pixel missed its mode or is not background: redo the frame below
-#pragma unroll
-            for (int q3 = 0; q3 < 3; q3++)
-                wa[q3] -= (uint32_t)TILE * 4u;
+            wa -= (uint32_t)TILE * 4u;
             break;
         }
         if (valid)
@@ -1758,7 +1783,8 @@ hipError_t mog2_apply(const uint8_t *frame, uint8_t *mask, const Mog2State &st, 
     // the same offset mod 4
     const bool aln = fused_blur3 && ((size_t)w * c) % 4 == 0 && fstride % 4 == 0 &&
                      ((size_t)h * w * c) % 4 == 0 && (uintptr_t)frame % 4 == 0;
-    if (aln && T > 1) {   // the multi-frame launch proper
+    // (its tap patterns add the outer taps where the border reflection folds them)
+    if (aln && T > 1 && w > 1 && t.kx[0] + t.kx[2] <= 255) {   // the multi-frame launch proper
         Mog2FramesArgs a;
         a.frame = frame;
         a.mask = mask;
