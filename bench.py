@@ -268,8 +268,9 @@ def main():
             key = {"streams": S, "height": h, "width": w, "frames_per_step": T}
             out["roofline"] = {
                 "bound": "hbm",
-                "kernel": "mog2_kernel<3,true,%s,true> (fused 3x3 blur + MOG2 update + classify, %d "
-                          "frame(s) per launch)" % ("true" if T > 1 else "false", min(T, 8)),
+                "kernel": "%s (fused 3x3 blur + MOG2 update + classify, %d frame(s) per launch)"
+                          % ("mog2_frames_kernel<3>" if T > 1 else "mog2_kernel<3,true,false,true>",
+                             min(T, 8)),
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": load_traffic(args.traffic_file, key),
