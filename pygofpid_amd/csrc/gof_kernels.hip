@@ -358,7 +358,7 @@ __device__ __forceinline__ uint8_t mog2_update_single(PixelModel<C> &M, int &nmo
 // `stay`: the wave is still settled after a committed frame.
 template <int C>
 __device__ __forceinline__ bool mog2_try_settled(PixelModel<C> &M, const float (&x)[C],
-                                                 const Mog2Consts &k, bool &stay)
+                                                 const Mog2Consts &k, float var_max_v, bool &stay)
 {
     constexpr uint32_t kOne = 0x3f800000u;
     const float var = M.var[0];
@@ -377,12 +377,16 @@ __device__ __forceinline__ bool mog2_try_settled(PixelModel<C> &M, const float (
             dist2 += d[c] * d[c];
         }
     }
-    const bool fit = dist2 < k.Tg * var;
-    const bool close = dist2 < k.Tb * var;
     const uint64_t all = __builtin_amdgcn_ballot_w64(true);
     // 0.f < TB on the scalar unit (a parameter, never NaN)
-    if (__float_as_int(k.TB) <= 0 || __builtin_amdgcn_ballot_w64(fit) != all ||
-        __builtin_amdgcn_ballot_w64(close) != all)
+    if (__float_as_int(k.TB) <= 0 || __builtin_amdgcn_ballot_w64(dist2 < k.Tg * var) != all)
+        return false;
+    // Every pixel fits.  It is background if also dist2 < Tb * var; for 0 < Tg <= Tb
+    // (positive floats order like their bit patterns; cv2's defaults are 9 and 16)
+    // that follows: dist2 >= 0, so a fit means Tg * var > 0, var > 0, and the
+    // product is monotonic in its first factor.
+    const bool implied = __float_as_int(k.Tg) > 0 && __float_as_int(k.Tb) >= __float_as_int(k.Tg);
+    if (!implied && __builtin_amdgcn_ballot_w64(dist2 < k.Tb * var) != all)
         return false;
 #pragma unroll
     for (int c = 0; c < C; c++)
@@ -390,10 +394,10 @@ __device__ __forceinline__ bool mog2_try_settled(PixelModel<C> &M, const float (
     // median of (v, var_min, var_max) instead of two compare + select pairs: the
     // same value for every v, NaN included, given var_min <= var_max (which the host
     // checks before it allows this path)
-    M.var[0] = __builtin_amdgcn_fmed3f(var + k.kk1 * (dist2 - var), k.var_min, k.var_max);
+    M.var[0] = __builtin_amdgcn_fmed3f(var + k.kk1 * (dist2 - var), k.var_min, var_max_v);
+    // the fitted weight; 1.0f again (what it was) whenever the wave stays settled
+    M.w[0] = k.wnfit;
     stay = __float_as_uint(k.wnfit) == kOne;
-    if (!stay)
-        M.w[0] = k.wnfit;
     return true;
 }
 
@@ -878,7 +882,8 @@ __global__ __launch_bounds__(256) void mog2_frames_kernel(const Mog2FramesArgs a
     }
     uint32_t wa = (uint32_t)(wave * ROWD) * 4u + (uint32_t)A;   // window address, current frame
     uint32_t half = 32768u;
-    asm volatile("" : "+v"(half));   // keep it in a register (not re-materialised per use)
+    float var_max_v = a.k.var_max;   // (the clamp takes one scalar operand, var_min)
+    asm volatile("" : "+v"(half), "+v"(var_max_v));   // kept in registers, not re-materialised per use
     const uint32_t ky[3] = {a.ky012 & 1023u, (a.ky012 >> 10) & 1023u, a.ky012 >> 20};
 
     __syncthreads();   // the only barrier: every tile is in LDS
@@ -961,7 +966,7 @@ __global__ __launch_bounds__(256) void mog2_frames_kernel(const Mog2FramesArgs a
         const Mog2Consts kt = frame_consts(rates);
         float xin[C];
         frame_input(xin, true);
-        if (!mog2_try_settled<C>(M, xin, kt, settled)) {
+        if (!mog2_try_settled<C>(M, xin, kt, var_max_v, settled)) {
             // some pixel missed its mode or is not background: redo the frame below
             wa -= (uint32_t)TILE * 4u;
             break;
