@@ -117,6 +117,7 @@ struct gof_pipeline {
     gof_mog2 *mog2 = nullptr;
     gof_fd *fd = nullptr;
     DevBuf in, out, blurred, m0, m1;
+    DevBuf rowflags;   // per launch chunk: [stream][h][tile column] bytes, see gofk::mog2_apply
     unsigned long long *d_sum = nullptr;
     // profiling: events[3*i+0..2] = before detector, after detector, after morphology
     bool prof = false;
@@ -975,6 +976,7 @@ int gof_pipeline_apply_dev_many(gof_pipeline *p, const void *d_frames, void *d_m
 
     // step 2 (pipeline.py:470)
     uint8_t *det_out = (uint8_t *)d_masks;
+    uint8_t *rf = nullptr;   // row flags of the detector masks (MOG2 multi-frame launches only)
     if (d.n_morph > 0) {
         if ((rc = p->m0.reserve((size_t)T * npx)))
             return rc;
@@ -982,16 +984,29 @@ int gof_pipeline_apply_dev_many(gof_pipeline *p, const void *d_frames, void *d_m
     }
     if (p->mog2) {
         // temporal blocking: up to kMaxT frames per launch, the model moves once
+        // row flags for the morphology (which 64-px mask segments are all zero), one
+        // plane per launch chunk; only worth having when a fused chain follows
+        const size_t rf_chunk = (size_t)d.streams * d.h * gofk::rowflag_pitch(d.w);
+        const int chunks = (T + gofk::kMaxT - 1) / gofk::kMaxT;
+        if (d.n_morph > 0 && p->chain_ok && T > 1) {
+            if ((rc = p->rowflags.reserve(rf_chunk * chunks)))
+                return rc;
+            rf = (uint8_t *)p->rowflags.p;
+        }
         for (int t0 = 0; t0 < T; t0 += gofk::kMaxT) {
             const int tn = T - t0 < gofk::kMaxT ? T - t0 : gofk::kMaxT;
             gofk::Mog2Consts k = next_consts(p->mog2, tn);
+            uint8_t *rfc = rf ? rf + (size_t)(t0 / gofk::kMaxT) * rf_chunk : nullptr;
+            bool written = false;
             hipError_t e = gofk::mog2_apply(x + (size_t)t0 * npx * d.c, det_out + (size_t)t0 * npx,
                                             p->mog2->view(), d.streams, d.h, d.w, d.c, tn, k,
-                                            p->fuse_blur3, p->taps, s);
+                                            p->fuse_blur3, p->taps, s, rfc, &written);
             if (e != hipSuccess) {
                 p->mog2->nframes -= tn;
                 return fail(GOF_EHIP, "mog2 launch: %s", hipGetErrorString(e));
             }
+            if (rfc && !written)   // a chunk another kernel handled: "nothing is known to be zero"
+                GOF_HIP(hipMemsetAsync(rfc, 0xFF, rf_chunk, s));
         }
     } else {
         for (int t = 0; t < T; t++)
@@ -1006,7 +1021,7 @@ int gof_pipeline_apply_dev_many(gof_pipeline *p, const void *d_frames, void *d_m
         if (p->chain_ok) {
             // detector masks are chain-valued ({0, shadow, 255} / {0, 84, 85} / {0, 255})
             GOF_HIP(gofk::morph_rect_chain(det_out, (uint8_t *)d_masks, T * d.streams, d.h, d.w,
-                                           p->chain, true, s));
+                                           p->chain, true, s, rf, d.streams));
         } else {
             if (d.n_morph > 1 && (rc = p->m1.reserve((size_t)T * npx)))
                 return rc;

@@ -89,9 +89,14 @@ hipError_t blur_sep_q8(const uint8_t *src, uint8_t *dst, int n_img, int h, int w
 // frame ti uses k.alphaT_f[ti] / k.prune_f[ti].
 // fused_blur3: each frame is first blurred with the 3x3 taps t (REFLECT_101)
 // inside the same kernel (LDS-staged tile), no intermediate image.
+// rowflags (may be NULL): n_img * h * rowflag_pitch(w) bytes.  When the multi-frame
+// kernel runs it writes, per image row and 64-px tile column, a byte whose bit t
+// says "the mask of frame t is not all zero there" (conservative) and sets
+// *rowflags_written; morph_rect_chain uses that to skip reading all-zero regions.
+inline int rowflag_pitch(int w) { return (w + 63) / 64; }
 hipError_t mog2_apply(const uint8_t *frame, uint8_t *mask, const Mog2State &st, int n_img, int h,
                       int w, int c, int T, const Mog2Consts &k, bool fused_blur3, const Taps &t,
-                      hipStream_t s);
+                      hipStream_t s, uint8_t *rowflags = nullptr, bool *rowflags_written = nullptr);
 
 hipError_t fd_apply(const uint8_t *cur, const uint8_t *prev, bool has_prev, int ithr,
                     uint8_t *mask, int n_img, int h, int w, int c, hipStream_t s);
@@ -102,8 +107,11 @@ hipError_t morph_generic(int op, const uint8_t *src, uint8_t *dst, int n_img, in
 // all ops rectangular with odd sizes: one kernel, intermediates stay on chip.
 // chain_valued: the caller guarantees that the mask's values form a chain under
 // bitwise inclusion (every mask MOG2 / FD produce does) -> AND/OR fast path.
+// rowflags / streams (optional): the images are [t][stream] masks of a detector
+// launch sequence whose row flags are rowflags[t / 8][stream][h][pitch], bit t % 8.
 hipError_t morph_rect_chain(const uint8_t *src, uint8_t *dst, int n_img, int h, int w,
-                            const RectChain &ch, bool chain_valued, hipStream_t s);
+                            const RectChain &ch, bool chain_valued, hipStream_t s,
+                            const uint8_t *rowflags = nullptr, int streams = 1);
 bool morph_rect_chain_supported(const RectChain &ch);
 
 // (h,w,c in {3,4}) -> (h,w) luma, BGR order unless rgb

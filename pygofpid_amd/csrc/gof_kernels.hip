@@ -727,6 +727,8 @@ struct Mog2FramesArgs {
     int H, W, T;
     uint32_t kxw;     // horizontal taps as bytes (k0 | k1 << 8 | k2 << 16)
     uint32_t ky012;   // vertical taps, 10 bits each
+    uint8_t *rowflags;   // [image][row][tile column] bytes, bit t = frame t's mask not all zero there (or NULL)
+    int flag_pitch;
     Mog2Consts k;
 };
 
@@ -956,6 +958,7 @@ __global__ __launch_bounds__(256) void mog2_frames_kernel(const Mog2FramesArgs a
     // Three frame loops, entered in this order and never re-entered: settled waves,
     // then waves whose pixels all have at most one mode, then the general update.
     int ti = 0;
+    uint32_t nz = 0;   // bit t: some mask byte of frame t is not zero in this wave (wave-uniform)
     u32x8 rates = load_rates(0);
     // settled on entry?  Afterwards mog2_try_settled reports it frame by frame.
     bool settled = __builtin_amdgcn_ballot_w64(!(nmodes == 1 && M.w[0] == 1.f)) == 0;
@@ -985,6 +988,7 @@ __global__ __launch_bounds__(256) void mog2_frames_kernel(const Mog2FramesArgs a
         float xin[C];
         frame_input(xin, true);
         const uint8_t out = mog2_update_single<C>(M, nmodes, xin, kt);
+        nz |= (__builtin_amdgcn_ballot_w64(out != 0) != 0 ? 1u : 0u) << ti;
         if (valid)
             *mp = out;
         mp += a.mask_stride;
@@ -1006,11 +1010,16 @@ __global__ __launch_bounds__(256) void mog2_frames_kernel(const Mog2FramesArgs a
         float xin[C];
         frame_input(xin, false);
         const uint8_t out = mog2_update<C, kMaxModes>(M, nmodes, xin, kt);
+        nz |= (__builtin_amdgcn_ballot_w64(out != 0) != 0 ? 1u : 0u) << ti;
         if (valid)
             *mp = out;
         mp += a.mask_stride;
         rates = next;
     }
+    // one flag byte per wave and launch for the morphology that follows (the settled
+    // loop only ever writes zeros, so it contributes no bits)
+    if (a.rowflags != nullptr && y < H && lane == 0)
+        a.rowflags[((size_t)img * H + y) * a.flag_pitch + blockIdx.x] = (uint8_t)nz;
     if (!valid)
         return;
 
@@ -1505,7 +1514,9 @@ __device__ __forceinline__ void stream_op_bits(uint32_t (&R)[NR], int rx_rt)
 template <int NR>
 __global__ __launch_bounds__(64) void morph_stream_bits_kernel(const uint8_t *__restrict__ src,
                                                                 uint8_t *__restrict__ dst, int H,
-                                                                int W, RectChain ch, int HQ, int RY)
+                                                                int W, RectChain ch, int HQ, int RY,
+                                                                const uint8_t *__restrict__ rowflags,
+                                                                int streams)
 {
     // dword-aligned images only (the launcher checks); same geometry as morph_stream_kernel
     const int lane = threadIdx.x;
@@ -1524,6 +1535,34 @@ __global__ __launch_bounds__(64) void morph_stream_bits_kernel(const uint8_t *__
     // interior strips never see the border: skip the identity re-imposition there
     const bool interior = __builtin_amdgcn_readfirstlane(
         (int)(sx0 - 4 * HQ >= 0 && sx0 - 4 * HQ + 256 <= W && Y0 >= 0 && Y0 + NR <= H));
+
+    // The detector said which 64-px row segments of its masks are all zero.  If
+    // every segment this strip reads (halo included) is, every output is zero too:
+    // a min / max over zeros and the ops' out-of-image identities (255 only under a
+    // min) is zero.  Then nothing is read -- most strips of a surveillance mask.
+    if (rowflags != nullptr) {
+        const int n = blockIdx.z, t = n / streams, st = n - t * streams;
+        const int pitch = (W + 63) >> 6;
+        const uint8_t *fp = rowflags + ((size_t)((t >> 3) * streams + st) * H) * pitch;
+        const int xa = sx0 - 4 * HQ < 0 ? 0 : sx0 - 4 * HQ;
+        const int xb = sx0 - 4 * HQ + 255 > W - 1 ? W - 1 : sx0 - 4 * HQ + 255;
+        const int gy = Y0 + (lane < NR ? lane : 0);
+        const int gyc = gy < 0 ? 0 : (gy > H - 1 ? H - 1 : gy);
+        uint32_t v = 0;
+        for (int cx = xa >> 6; cx <= (xb >> 6); cx++)   // at most 5 tile columns
+            v |= fp[(size_t)gyc * pitch + cx];
+        if (__builtin_amdgcn_ballot_w64(((v >> (t & 7)) & 1u) != 0) == 0) {
+            if (lane >= HQ && lane < 64 - HQ && gx0 < W) {
+#pragma unroll
+                for (int j = 0; j < NR; j++) {
+                    const int oy = y0 + j;
+                    if (j < rows_out && oy < H)
+                        *(uint32_t *)(dimg + (size_t)oy * W + gx0) = 0u;
+                }
+            }
+            return;
+        }
+    }
 
     uint32_t R[NR];
     const int gxc = gx0 < 0 ? 0 : (gx0 > W - 4 ? W - 4 : gx0);
@@ -1769,8 +1808,10 @@ hipError_t blur_sep_q8(const uint8_t *src, uint8_t *dst, int n_img, int h, int w
 
 hipError_t mog2_apply(const uint8_t *frame, uint8_t *mask, const Mog2State &st, int n_img, int h,
                       int w, int c, int T, const Mog2Consts &k, bool fused_blur3, const Taps &t,
-                      hipStream_t s)
+                      hipStream_t s, uint8_t *rowflags, bool *rowflags_written)
 {
+    if (rowflags_written)
+        *rowflags_written = false;
     if (n_img < 1 || h < 1 || w < 1 || (h + TH - 1) / TH > 65535 || n_img > 65535 ||
         st.np < (size_t)n_img * h * w || k.nmix < 1 || k.nmix > kMaxModes || T < 1 || T > kMaxT)
         return hipErrorInvalidValue;
@@ -1803,6 +1844,10 @@ hipError_t mog2_apply(const uint8_t *frame, uint8_t *mask, const Mog2State &st, 
         a.T = T;
         a.kxw = (uint32_t)t.kx[0] | ((uint32_t)t.kx[1] << 8) | ((uint32_t)t.kx[2] << 16);
         a.ky012 = ky;
+        a.rowflags = rowflags;
+        a.flag_pitch = rowflag_pitch(w);
+        if (rowflags_written)
+            *rowflags_written = rowflags != nullptr;
         a.k = k;
         switch (c) {
         case 1: hipLaunchKernelGGL(mog2_frames_kernel<1>, g, dim3(256), 0, s, a); break;
@@ -1924,7 +1969,8 @@ bool stream_geometry(const RectChain &ch, int *HQ, int *RY)
 }  // namespace
 
 hipError_t morph_rect_chain(const uint8_t *src, uint8_t *dst, int n_img, int h, int w,
-                            const RectChain &ch, bool chain_valued, hipStream_t s)
+                            const RectChain &ch, bool chain_valued, hipStream_t s,
+                            const uint8_t *rowflags, int streams)
 {
     int HQ, RY;
     size_t lds;
@@ -1941,12 +1987,14 @@ hipError_t morph_rect_chain(const uint8_t *src, uint8_t *dst, int n_img, int h, 
         dim3 g((unsigned)((w + strip_px - 1) / strip_px), (unsigned)((h + rows_out - 1) / rows_out),
                (unsigned)n_img);
         static const bool no_bits = getenv("GOF_MORPH_NOBITS") != nullptr;   // A/B knob
+        static const bool no_skip = getenv("GOF_MORPH_NOSKIP") != nullptr;   // A/B knob
+        const uint8_t *rf = (no_skip || streams < 1 || n_img % (streams < 1 ? 1 : streams)) ? nullptr : rowflags;
         if (chain_valued && fast && !no_bits) {
             switch (NR) {
-            case 16: hipLaunchKernelGGL(morph_stream_bits_kernel<16>, g, dim3(64), 0, s, src, dst, h, w, ch, HQ, RY); break;
-            case 24: hipLaunchKernelGGL(morph_stream_bits_kernel<24>, g, dim3(64), 0, s, src, dst, h, w, ch, HQ, RY); break;
-            case 32: hipLaunchKernelGGL(morph_stream_bits_kernel<32>, g, dim3(64), 0, s, src, dst, h, w, ch, HQ, RY); break;
-            case 48: hipLaunchKernelGGL(morph_stream_bits_kernel<48>, g, dim3(64), 0, s, src, dst, h, w, ch, HQ, RY); break;
+            case 16: hipLaunchKernelGGL(morph_stream_bits_kernel<16>, g, dim3(64), 0, s, src, dst, h, w, ch, HQ, RY, rf, streams); break;
+            case 24: hipLaunchKernelGGL(morph_stream_bits_kernel<24>, g, dim3(64), 0, s, src, dst, h, w, ch, HQ, RY, rf, streams); break;
+            case 32: hipLaunchKernelGGL(morph_stream_bits_kernel<32>, g, dim3(64), 0, s, src, dst, h, w, ch, HQ, RY, rf, streams); break;
+            case 48: hipLaunchKernelGGL(morph_stream_bits_kernel<48>, g, dim3(64), 0, s, src, dst, h, w, ch, HQ, RY, rf, streams); break;
             default: return hipErrorInvalidValue;
             }
             return hipGetLastError();
