@@ -415,6 +415,33 @@ def test_multi_frame_kernel_other_rates(oracle, over):
     _assert_state_equal(gpu.mog2_state(), want)
 
 
+@pytest.mark.parametrize("T", [8, 9, 11])
+def test_morphology_skips_only_empty_regions(oracle, T):
+    """The multi-frame MOG2 launch tells the morphology which 64-px row segments of
+    its masks are all zero, and strips whose whole input window is flagged empty are
+    written as zeros without being read.  Wide, mostly empty frames (several strips
+    per row, small objects that cross strip and tile boundaries), full launches, a
+    partial second launch (T = 11) and a one-frame tail that the per-frame kernel
+    handles and that must switch the skipping off for its chunk (T = 9)."""
+    from pygofpid_amd.foreground import ForegroundPipeline
+    h, w, c, S = 100, 520, 3, 2
+    clips = [Clip(h, w, c, seed=500 + s, n_objects=2, speed=5) for s in range(S)]
+    gpu = ForegroundPipeline((h, w, c), streams=S)
+    refs = [oracle.Pipeline(h, w, c) for _ in range(S)]
+    t = 0
+    empty = 0
+    for _ in range(3):
+        frames = np.stack([np.stack([cl.frame(t + i) for cl in clips]) for i in range(T)])
+        got = gpu.apply_many(frames).reshape(T, S, h, w)
+        for i in range(T):
+            for s in range(S):
+                want = refs[s].apply(frames[i, s])
+                assert np.array_equal(got[i, s], want), (T, t + i, s, int((got[i, s] != want).sum()))
+                empty += int(not want[:, :248].any()) + int(not want[:, 248:].any())
+        t += T
+    assert empty > 0   # the scene did contain empty strips-worth of mask
+
+
 def test_pipeline_temporal_blocking_other_paths(oracle):
     """apply_many through the unfused blur, the FD detector and a grey stream."""
     from pygofpid_amd.foreground import ForegroundPipeline
