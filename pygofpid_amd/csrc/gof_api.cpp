@@ -988,6 +988,8 @@ int gof_pipeline_apply_dev_many(gof_pipeline *p, const void *d_frames, void *d_m
         // plane per launch chunk; only worth having when a fused chain follows
         const size_t rf_chunk = (size_t)d.streams * d.h * gofk::rowflag_pitch(d.w);
         const int chunks = (T + gofk::kMaxT - 1) / gofk::kMaxT;
+        // (one-frame calls go without: there the flag store costs the detector what the
+        // skipping saves the morphology)
         if (d.n_morph > 0 && p->chain_ok && T > 1) {
             if ((rc = p->rowflags.reserve(rf_chunk * chunks)))
                 return rc;

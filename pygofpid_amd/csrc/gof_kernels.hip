@@ -424,13 +424,14 @@ __device__ __forceinline__ int reflect1(int p, int len)
 // pitch and frame pitch multiples of 4, 4-byte aligned base -- the launcher
 // checks), so the lane's window addresses and byte shifts are loop invariants.
 template <int C, bool BLUR3, bool MULTI, bool ALN>
-__global__ __launch_bounds__(256) void mog2_kernel(const uint8_t *__restrict__ frame,
+__global__ __launch_bounds__(256, (!MULTI && ALN && C <= 3) ? 8 : 1) void mog2_kernel(const uint8_t *__restrict__ frame,
                                                    uint8_t *__restrict__ mask,
                                                    float *__restrict__ planes,
                                                    uint8_t *__restrict__ modes, size_t np, int H,
                                                    int W, int T_arg, size_t frame_stride,
                                                    size_t mask_stride, Mog2Consts k, uint32_t kx012,
-                                                   uint32_t ky012)
+                                                   uint32_t ky012, uint8_t *__restrict__ rowflags,
+                                                   int flag_pitch)
 {
     constexpr int F = 2 + C;  // floats per mode
     const int T = MULTI ? T_arg : 1;
@@ -657,23 +658,35 @@ __global__ __launch_bounds__(256) void mog2_kernel(const uint8_t *__restrict__ f
     // the registers; the first frame that sees a second mode anywhere in the wave
     // hands the rest of the launch to the general loop.
     int ti = 0;
+    uint32_t nz = 0;
     for (; ti < T; ti++) {
         if (__builtin_amdgcn_ballot_w64(nmodes > 1) != 0)
             break;
         float xin[C];
         frame_input(ti, xin);
         const Mog2Consts kt = frame_consts(ti);
-        if (valid)
-            mask[(size_t)ti * mask_stride + rowoff + xl] = mog2_update_single<C>(M, nmodes, xin, kt);
+        uint8_t out = 0;
+        if (valid) {
+            out = mog2_update_single<C>(M, nmodes, xin, kt);
+            mask[(size_t)ti * mask_stride + rowoff + xl] = out;
+        }
+        nz |= (__builtin_amdgcn_ballot_w64(out != 0) != 0 ? 1u : 0u) << ti;
     }
     for (; ti < T; ti++) {
         float xin[C];
         frame_input(ti, xin);
         const Mog2Consts kt = frame_consts(ti);
-        if (valid)
-            mask[(size_t)ti * mask_stride + rowoff + xl] =
-                mog2_update<C, kMaxModes>(M, nmodes, xin, kt);
+        uint8_t out = 0;
+        if (valid) {
+            out = mog2_update<C, kMaxModes>(M, nmodes, xin, kt);
+            mask[(size_t)ti * mask_stride + rowoff + xl] = out;
+        }
+        nz |= (__builtin_amdgcn_ballot_w64(out != 0) != 0 ? 1u : 0u) << ti;
     }
+    // one flag byte per wave and launch for the morphology that follows: bit t =
+    // some mask byte of frame t is not zero in this 64-px row segment
+    if (rowflags != nullptr && rowok && lane == 0)
+        rowflags[((size_t)img * H + y) * flag_pitch + blockIdx.x] = (uint8_t)nz;
     if (!valid)
         return;
 
@@ -1811,7 +1824,7 @@ hipError_t mog2_apply(const uint8_t *frame, uint8_t *mask, const Mog2State &st, 
                       hipStream_t s, uint8_t *rowflags, bool *rowflags_written)
 {
     if (rowflags_written)
-        *rowflags_written = false;
+        *rowflags_written = rowflags != nullptr;   // every MOG2 kernel writes them
     if (n_img < 1 || h < 1 || w < 1 || (h + TH - 1) / TH > 65535 || n_img > 65535 ||
         st.np < (size_t)n_img * h * w || k.nmix < 1 || k.nmix > kMaxModes || T < 1 || T > kMaxT)
         return hipErrorInvalidValue;
@@ -1846,8 +1859,6 @@ hipError_t mog2_apply(const uint8_t *frame, uint8_t *mask, const Mog2State &st, 
         a.ky012 = ky;
         a.rowflags = rowflags;
         a.flag_pitch = rowflag_pitch(w);
-        if (rowflags_written)
-            *rowflags_written = rowflags != nullptr;
         a.k = k;
         switch (c) {
         case 1: hipLaunchKernelGGL(mog2_frames_kernel<1>, g, dim3(256), 0, s, a); break;
@@ -1859,7 +1870,8 @@ hipError_t mog2_apply(const uint8_t *frame, uint8_t *mask, const Mog2State &st, 
     }
 #define GOF_LAUNCH_MOG2_(CC, BB, MM, AA)                                                         \
     hipLaunchKernelGGL((mog2_kernel<CC, BB, MM, AA>), g, dim3(256), 0, s, frame, mask,           \
-                       st.planes, st.modes, st.np, h, w, T, fstride, mstride, k, kx, ky)
+                       st.planes, st.modes, st.np, h, w, T, fstride, mstride, k, kx, ky, rowflags,      \
+                       rowflag_pitch(w))
 #define GOF_LAUNCH_MOG2(CC, BB)                                                                  \
     do {                                                                                         \
         if (T == 1 && aln)                                                                       \
