@@ -1007,8 +1007,8 @@ int gof_pipeline_apply_dev_many(gof_pipeline *p, const void *d_frames, void *d_m
                 p->mog2->nframes -= tn;
                 return fail(GOF_EHIP, "mog2 launch: %s", hipGetErrorString(e));
             }
-            if (rfc && !written)   // a chunk another kernel handled: "nothing is known to be zero"
-                GOF_HIP(hipMemsetAsync(rfc, 0xFF, rf_chunk, s));
+            if (rfc && !written)   // (every MOG2 kernel writes them today; keep the contract explicit)
+                GOF_HIP(hipMemsetAsync(rfc, 0xFF, rf_chunk, s));   // "nothing is known to be zero"
         }
     } else {
         for (int t = 0; t < T; t++)
