@@ -110,7 +110,8 @@ struct gof_pipeline {
     gof_pipeline_desc d{};
     std::vector<std::vector<uint8_t>> se;   // owned copies of the structuring elements
     gofk::Taps taps{};
-    bool fuse_blur3 = false;
+    bool fuse_blur3 = false;   // MOG2: the 3x3 blur runs inside the detector kernel
+    bool fuse_fd3 = false;     // FD: likewise, when the frames are aligned (checked per call)
     bool chain_ok = false;
     gofk::RectChain chain{};
     std::vector<gofk::SeBits> sebits;
@@ -118,6 +119,12 @@ struct gof_pipeline {
     gof_fd *fd = nullptr;
     DevBuf in, out, blurred, m0, m1;
     DevBuf rowflags;   // per launch chunk: [stream][h][tile column] bytes, see gofk::mog2_apply
+    // fused blur + FD: the blurred last frame of the previous launch, one dword per
+    // pixel (ping-pong), and which path this pipeline took on its first call
+    DevBuf fd_prev[2];
+    int fd_cur = 0;
+    bool fd_has_prev = false;
+    int fd_mode = 0;   // 0 undecided, 1 fused kernel, 2 separate blur / difference kernels
     unsigned long long *d_sum = nullptr;
     // profiling: events[3*i+0..2] = before detector, after detector, after morphology
     bool prof = false;
@@ -883,6 +890,7 @@ int gof_pipeline_create(gof_ctx *ctx, const gof_pipeline_desc *desc, gof_pipelin
         // sigma gives [0, 256, 0], which goes through the generic blur instead)
         p->fuse_blur3 = desc->detector == GOF_DET_MOG2 && p->taps.nkx == 3 && p->taps.nky == 3 &&
                         p->taps.kx[0] < 256 && p->taps.kx[1] < 256 && p->taps.kx[2] < 256;
+        p->fuse_fd3 = desc->detector == GOF_DET_FD;   // geometry / taps: fd_frames_supported()
     } else if (desc->blur == GOF_BLUR_BOX) {
         if ((rc = make_box(desc->blur_kw, desc->blur_kh, &p->taps)))
             return bail(rc);
@@ -962,7 +970,19 @@ int gof_pipeline_apply_dev_many(gof_pipeline *p, const void *d_frames, void *d_m
 
     // step 1 (pipeline.py:462-467) -- unless it is fused into step 2
     const uint8_t *x = (const uint8_t *)d_frames;
-    if (d.blur != GOF_BLUR_NONE && !p->fuse_blur3) {
+    // FD: the fused kernel needs aligned frames.  The choice is made on the first
+    // call and kept (the two paths keep the previous frame in different formats); a
+    // later misaligned pointer is copied to an aligned buffer first.
+    if (p->fuse_fd3 && p->fd && p->fd_mode == 0)
+        p->fd_mode = gofk::fd_frames_supported(x, d.streams, d.h, d.w, d.c, p->taps) ? 1 : 2;
+    const bool fd_fused = p->fd_mode == 1;
+    if (fd_fused && !gofk::fd_frames_supported(x, d.streams, d.h, d.w, d.c, p->taps)) {
+        if ((rc = p->in.reserve((size_t)T * npx * d.c)))
+            return rc;
+        GOF_HIP(hipMemcpyAsync(p->in.p, x, (size_t)T * npx * d.c, hipMemcpyDeviceToDevice, s));
+        x = (const uint8_t *)p->in.p;
+    }
+    if (d.blur != GOF_BLUR_NONE && !p->fuse_blur3 && !fd_fused) {
         if ((rc = p->blurred.reserve((size_t)T * npx * d.c)))
             return rc;
         GOF_HIP(gofk::blur_sep_q8(x, (uint8_t *)p->blurred.p, T * d.streams, d.h, d.w, d.c, p->taps, s));
@@ -1009,6 +1029,29 @@ int gof_pipeline_apply_dev_many(gof_pipeline *p, const void *d_frames, void *d_m
             }
             if (rfc && !written)   // (every MOG2 kernel writes them today; keep the contract explicit)
                 GOF_HIP(hipMemsetAsync(rfc, 0xFF, rf_chunk, s));   // "nothing is known to be zero"
+        }
+    } else if (fd_fused) {
+        // blur + difference for up to kMaxT frames per launch; the blurred last frame is
+        // handed from launch to launch in fd_prev
+        const size_t bytes = npx * d.c;
+        if ((rc = p->fd_prev[0].reserve(npx * 4)) || (rc = p->fd_prev[1].reserve(npx * 4)))
+            return rc;
+        const size_t rf_chunk = (size_t)d.streams * d.h * gofk::rowflag_pitch(d.w);
+        if (d.n_morph > 0 && p->chain_ok && T > 1) {
+            if ((rc = p->rowflags.reserve(rf_chunk * ((T + gofk::kMaxT - 1) / gofk::kMaxT))))
+                return rc;
+            rf = (uint8_t *)p->rowflags.p;
+        }
+        for (int t0 = 0; t0 < T; t0 += gofk::kMaxT) {
+            const int tn = T - t0 < gofk::kMaxT ? T - t0 : gofk::kMaxT;
+            GOF_HIP(gofk::fd_frames_apply(x + (size_t)t0 * bytes, det_out + (size_t)t0 * npx,
+                                          (const uint32_t *)p->fd_prev[p->fd_cur ^ 1].p,
+                                          (uint32_t *)p->fd_prev[p->fd_cur].p, p->fd_has_prev,
+                                          fd_ithr(p->fd->threshold), d.streams, d.h, d.w, d.c, tn,
+                                          p->taps, s,
+                                          rf ? rf + (size_t)(t0 / gofk::kMaxT) * rf_chunk : nullptr));
+            p->fd_cur ^= 1;
+            p->fd_has_prev = true;
         }
     } else {
         for (int t = 0; t < T; t++)

@@ -101,6 +101,16 @@ hipError_t mog2_apply(const uint8_t *frame, uint8_t *mask, const Mog2State &st, 
 hipError_t fd_apply(const uint8_t *cur, const uint8_t *prev, bool has_prev, int ithr,
                     uint8_t *mask, int n_img, int h, int w, int c, hipStream_t s);
 
+// GaussianBlur 3x3 (taps t) + frame differencing for T <= kMaxT consecutive frames
+// [T][n_img][h][w][c] in one launch; the blurred last frame is handed from launch
+// to launch through prev_in / prev_out (one dword per pixel, n_img*h*w of them each,
+// distinct buffers; the kernels' own format).
+// fd_frames_supported: 3x3 byte taps, aligned rows / frames (as the fused MOG2 path).
+bool fd_frames_supported(const uint8_t *frame, int n_img, int h, int w, int c, const Taps &t);
+hipError_t fd_frames_apply(const uint8_t *frame, uint8_t *mask, const uint32_t *prev_in,
+                           uint32_t *prev_out, bool has_prev, int ithr, int n_img, int h, int w, int c,
+                           int T, const Taps &t, hipStream_t s, uint8_t *rowflags = nullptr);
+
 hipError_t morph_generic(int op, const uint8_t *src, uint8_t *dst, int n_img, int h, int w,
                          const SeBits &se, hipStream_t s);
 

@@ -731,6 +731,162 @@ __global__ __launch_bounds__(256, (!MULTI && ALN && C <= 3) ? 8 : 1) void mog2_k
 //     host-evaluated weight arithmetic (FrameRates) instead of two division
 //     chains per lane.
 // ---------------------------------------------------------------------------
+// ---- pieces the multi-frame kernels share -------------------------------------
+// Geometry of the staged tiles: (TH + 2) x (TW + 2) px of each of up to kMaxT frames,
+// raw bytes, LDS rows of a 64-dword pitch per 64 lanes.
+template <int C, int NT = kMaxT>
+struct FrameTiles {
+    static constexpr int NDW = (((TW + 2) * C + 3 + 3) / 4 + 1 + 63) / 64;   // dwords per lane and staged row
+    static constexpr int ROWD = NDW * 64;   // LDS row pitch in dwords: every lane writes, no predicate
+    static constexpr int TILE = (TH + 2) * ROWD;
+    static constexpr int LDS_DWORDS = NT * TILE;
+    int sx0;    // first staged image column
+    int mis0;   // byte offset of that column's pixel within its aligned dword (same in every row / frame)
+
+    // Issue the loads of rows {wave, wave + 4} of all frames: two running row
+    // pointers (every staged row of every frame has the same offset mod 4, which the
+    // launcher checks), one shared lane offset, no predicates -- lanes past the
+    // row's last dword re-read it, frames past T re-read frame T - 1.
+    __device__ __forceinline__ void load(const uint8_t *frame, size_t frame_stride, int H, int W, int T,
+                                         int img, int x0, int y0, int wave, int lane,
+                                         uint32_t (&raw)[NT][2][NDW])
+    {
+        const size_t N = (size_t)H * W;
+        sx0 = x0 > 0 ? x0 - 1 : 0;
+        const int sx1 = (x0 + TW + 1) < W ? (x0 + TW + 1) : W;
+        const int nb = (sx1 - sx0) * C;
+        const uint8_t *img0 = frame + (size_t)img * N * C;
+        mis0 = (int)((uintptr_t)(img0 + (size_t)sx0 * C) & 3);
+        const int ndw = (mis0 + nb + 3) >> 2;
+        typedef const uint8_t __attribute__((address_space(1))) *GlobalBytes;
+        GlobalBytes rowp[2];
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++) {
+            const int r = wave + 4 * rr;
+            const int gy = reflect1(y0 - 1 + (r < TH + 2 ? r : 0), H);
+            const int gyc = gy < H ? gy : H - 1;   // rows below a ragged last tile
+            rowp[rr] = (GlobalBytes)(img0 + ((size_t)gyc * W + sx0) * C - mis0);
+        }
+#pragma unroll
+        for (int ti = 0; ti < NT; ti++) {
+            const size_t step = ti + 1 < T ? frame_stride : 0;
+#pragma unroll
+            for (int rr = 0; rr < 2; rr++) {
+#pragma unroll
+                for (int q = 0; q < NDW; q++) {
+                    const unsigned d = lane + 64 * q < ndw ? lane + 64 * q : ndw - 1;
+                    raw[ti][rr][q] = *(const uint32_t __attribute__((address_space(1))) *)(rowp[rr] + d * 4u);   // SGPR base + 32-bit lane offset
+                }
+                rowp[rr] += step;
+            }
+        }
+    }
+
+    __device__ __forceinline__ static void store(uint32_t *tiles, int wave, int lane,
+                                                 const uint32_t (&raw)[NT][2][NDW])
+    {
+#pragma unroll
+        for (int ti = 0; ti < NT; ti++) {
+#pragma unroll
+            for (int rr = 0; rr < 2; rr++) {
+                const int r = wave + 4 * rr;
+                if (r < TH + 2) {
+#pragma unroll
+                    for (int q = 0; q < NDW; q++)
+                        tiles[ti * TILE + r * ROWD + lane + 64 * q] = raw[ti][rr][q];
+                }
+            }
+        }
+    }
+};
+
+// Lane-invariant blur addressing.  The three pixels a lane needs from a staged row
+// (left, centre, right; the border reflection can fold left onto right) lie within
+// 12 bytes of the aligned address A below the leftmost of them.  Instead of
+// extracting them (alignbyte + byte permutes), the lane carries, per channel, a
+// 12-byte tap pattern: the horizontal pass of a row is then three v_dot4_u32_u8 per
+// channel on the three aligned dwords, nothing else.  xc: the lane's image column
+// (a lane outside the image passes the tile's first column).
+template <int C>
+struct TapPatterns {
+    uint32_t pat[C][3];
+    int A;   // byte offset of the window within a staged row
+
+    __device__ __forceinline__ void build(int xc, int W, int sx0, int mis0, uint32_t kxw)
+    {
+        const int pl = (reflect1(xc - 1, W) - sx0) * C + mis0, pc = (xc - sx0) * C + mis0,
+                  pr = (reflect1(xc + 1, W) - sx0) * C + mis0;
+        const int pmin = pl < pc ? (pl < pr ? pl : pr) : (pc < pr ? pc : pr);
+        A = pmin & ~3;
+        // channel 0: byte k0 at pl - A, k1 at pc - A, k2 at pr - A (k0 + k2 where the
+        // reflection folds them; the launcher checks that the sum fits a byte),
+        // as a 96-bit number (lo, hi); channel c is that number shifted by c bytes
+        const uint32_t kx[3] = {kxw & 255u, (kxw >> 8) & 255u, (kxw >> 16) & 255u};
+        const int rel[3] = {pl - A, pc - A, pr - A};   // each 0 .. 3 + 2 C
+        uint64_t lo = 0;
+        uint32_t hi = 0;
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+            const uint32_t sh = 8u * (uint32_t)(rel[t] & 7);
+            if (rel[t] < 8)
+                lo += (uint64_t)kx[t] << sh;
+            else
+                hi += kx[t] << sh;
+        }
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const uint64_t l = c ? lo << (8 * c) : lo;
+            const uint32_t h = c ? (hi << (8 * c)) | (uint32_t)(lo >> (64 - 8 * c)) : hi;
+            pat[c][0] = (uint32_t)l;
+            pat[c][1] = (uint32_t)(l >> 32);
+            pat[c][2] = h;
+        }
+    }
+
+    // blurred pixel from the 3 x 3 aligned dwords at window address wa of a tile:
+    // horizontal pass as dot products against the patterns, vertical pass as 24-bit
+    // multiply-adds onto the rounding constant (`half`, 2^15 in a VGPR: the
+    // multiply-add takes one scalar operand), >> 16 -- the integer of the separable
+    // 8.8 blur of blur_kernel (sums of the same products, no intermediate rounding)
+    template <int ROWD>
+    __device__ __forceinline__ void blur(const uint32_t *tiles, uint32_t wa, const uint32_t (&ky)[3],
+                                         uint32_t half, bool batch, uint32_t (&out)[C]) const
+    {
+        uint32_t win[3][3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const uint32_t *q = (const uint32_t *)((const char *)tiles + wa + (uint32_t)(j * ROWD) * 4u);
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+                win[j][i] = q[i];
+        }
+        // keeps all nine live at one point: the reads are issued back to back
+        if (batch)
+            asm volatile(""
+                         : "+v"(win[0][0]), "+v"(win[0][1]), "+v"(win[0][2]), "+v"(win[1][0]),
+                           "+v"(win[1][1]), "+v"(win[1][2]), "+v"(win[2][0]), "+v"(win[2][1]),
+                           "+v"(win[2][2]));
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            uint32_t acc = half;
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                uint32_t h = __builtin_amdgcn_udot4(win[j][0], pat[c][0], 0u, false);
+                h = __builtin_amdgcn_udot4(win[j][1], pat[c][1], h, false);
+                h = __builtin_amdgcn_udot4(win[j][2], pat[c][2], h, false);
+                // acc += ky[j] * h as ONE v_mad_u32_u24 (h < 2^16, ky < 2^10).  The empty
+                // asm pins the running sum: without it the three products are
+                // re-associated into multiply, multiply-add, multiply, three-way add.
+                // (The multiply-add itself must stay compiler-generated: a VALU read of
+                // a v_dot4 result needs wait states that only the compiler inserts.)
+                acc = __umul24(ky[j], h) + acc;
+                asm volatile("" : "+v"(acc));
+            }
+            out[c] = acc >> 16;
+        }
+    }
+};
+
 struct Mog2FramesArgs {
     const uint8_t *frame;
     uint8_t *mask;
@@ -749,10 +905,9 @@ template <int C>
 __global__ __launch_bounds__(256) void mog2_frames_kernel(const Mog2FramesArgs a)
 {
     constexpr int F = 2 + C;
-    constexpr int NDW = (((TW + 2) * C + 3 + 3) / 4 + 1 + 63) / 64;   // dwords per lane and staged row
-    constexpr int ROWD = NDW * 64;   // LDS row pitch in dwords: every lane writes, no predicate
-    constexpr int TILE = (TH + 2) * ROWD;
-    __shared__ uint32_t tiles[kMaxT * TILE];
+    typedef FrameTiles<C> Tiles;
+    constexpr int ROWD = Tiles::ROWD, TILE = Tiles::TILE;
+    __shared__ uint32_t tiles[Tiles::LDS_DWORDS];
 
     const int H = a.H, W = a.W, T = a.T;
     const int lane = threadIdx.x & 63;
@@ -762,40 +917,11 @@ __global__ __launch_bounds__(256) void mog2_frames_kernel(const Mog2FramesArgs a
     const int x = x0 + lane, y = y0 + wave;
     const size_t N = (size_t)H * W;
 
-    // ---- stage the (TH+2) x (TW+2) px tiles of all T frames: raw bytes, aligned
-    //      dword loads, rows {wave, wave+4}; borders are resolved at read time ----
-    const int sx0 = x0 > 0 ? x0 - 1 : 0;
-    const int sx1 = (x0 + TW + 1) < W ? (x0 + TW + 1) : W;
-    const int nb = (sx1 - sx0) * C;
-    const uint8_t *img0 = a.frame + (size_t)img * N * C;
-    const int mis0 = (int)((uintptr_t)(img0 + (size_t)sx0 * C) & 3);   // of every staged row
-    const int ndw = (mis0 + nb + 3) >> 2;
-    typedef const uint8_t __attribute__((address_space(1))) *GlobalBytes;
-    GlobalBytes rowp[2];
-#pragma unroll
-    for (int rr = 0; rr < 2; rr++) {
-        const int r = wave + 4 * rr;
-        const int gy = reflect1(y0 - 1 + (r < TH + 2 ? r : 0), H);
-        const int gyc = gy < H ? gy : H - 1;   // rows below a ragged last tile
-        rowp[rr] = (GlobalBytes)(img0 + ((size_t)gyc * W + sx0) * C - mis0);
-    }
-    // straight-line: frames past T re-read frame T-1 (the pointers stop advancing),
-    // so the 2 * kMaxT loads need no branch and share one lane offset
-    uint32_t raw[kMaxT][2][NDW];
-#pragma unroll
-    for (int ti = 0; ti < kMaxT; ti++) {
-        const size_t step = ti + 1 < T ? a.frame_stride : 0;
-#pragma unroll
-        for (int rr = 0; rr < 2; rr++) {
-#pragma unroll
-            for (int q = 0; q < NDW; q++) {
-                // lanes past the row's last dword re-read it (never selected later)
-                const unsigned d = lane + 64 * q < ndw ? lane + 64 * q : ndw - 1;
-                raw[ti][rr][q] = *(const uint32_t __attribute__((address_space(1))) *)(rowp[rr] + d * 4u);   // SGPR base + 32-bit lane offset
-            }
-            rowp[rr] += step;
-        }
-    }
+    // ---- stage the tiles of all T frames (loads now, LDS writes after the model
+    //      loads are in flight); borders are resolved at read time ----
+    Tiles ft;
+    uint32_t raw[kMaxT][2][Tiles::NDW];
+    ft.load(a.frame, a.frame_stride, H, W, T, img, x0, y0, wave, lane, raw);
 
     // ---- model: mode count + mode 0 speculatively, the rest only if present ----
     const bool valid = y < H && x < W;
@@ -843,59 +969,12 @@ __global__ __launch_bounds__(256) void mog2_frames_kernel(const Mog2FramesArgs a
             M.mu[1][c] = 0.f;
     }
 
-    // tiles to LDS (after the model loads are in flight)
-#pragma unroll
-    for (int ti = 0; ti < kMaxT; ti++) {
-#pragma unroll
-        for (int rr = 0; rr < 2; rr++) {
-            const int r = wave + 4 * rr;
-            if (r < TH + 2) {
-#pragma unroll
-                for (int q = 0; q < NDW; q++)
-                    tiles[ti * TILE + r * ROWD + lane + 64 * q] = raw[ti][rr][q];
-            }
-        }
-    }
+    Tiles::store(tiles, wave, lane, raw);
 
-    // Lane-invariant blur addressing.  The three pixels a lane needs from a staged
-    // row (left, centre, right; the border reflection can fold left onto right) lie
-    // within 12 bytes of the aligned address A below the leftmost of them.  Instead
-    // of extracting them (alignbyte + byte permutes), the lane carries, per channel,
-    // a 12-byte tap pattern: the horizontal pass of a row is then three
-    // v_dot4_u32_u8 per channel on the three aligned dwords, nothing else.
-    // a lane outside the image shadows the tile's first pixel
-    const int xc = valid ? x : x0;
-    const int pl = (reflect1(xc - 1, W) - sx0) * C + mis0, pc = (xc - sx0) * C + mis0,
-              pr = (reflect1(xc + 1, W) - sx0) * C + mis0;
-    const int pmin = pl < pc ? (pl < pr ? pl : pr) : (pc < pr ? pc : pr);
-    const int A = pmin & ~3;
-    uint32_t pat[C][3];
-    {
-        // channel 0: byte k0 at pl - A, k1 at pc - A, k2 at pr - A (k0 + k2 where the
-        // reflection folds them; the launcher checks that the sum fits a byte),
-        // as a 96-bit number (lo, hi); channel c is that number shifted by c bytes
-        const uint32_t kx[3] = {a.kxw & 255u, (a.kxw >> 8) & 255u, (a.kxw >> 16) & 255u};
-        const int rel[3] = {pl - A, pc - A, pr - A};   // each 0 .. 3 + 2 C
-        uint64_t lo = 0;
-        uint32_t hi = 0;
-#pragma unroll
-        for (int t = 0; t < 3; t++) {
-            const uint32_t sh = 8u * (uint32_t)(rel[t] & 7);
-            if (rel[t] < 8)
-                lo += (uint64_t)kx[t] << sh;
-            else
-                hi += kx[t] << sh;
-        }
-#pragma unroll
-        for (int c = 0; c < C; c++) {
-            const uint64_t l = c ? lo << (8 * c) : lo;
-            const uint32_t h = c ? (hi << (8 * c)) | (uint32_t)(lo >> (64 - 8 * c)) : hi;
-            pat[c][0] = (uint32_t)l;
-            pat[c][1] = (uint32_t)(l >> 32);
-            pat[c][2] = h;
-        }
-    }
-    uint32_t wa = (uint32_t)(wave * ROWD) * 4u + (uint32_t)A;   // window address, current frame
+    // lane-invariant tap patterns; a lane outside the image shadows the tile's first pixel
+    TapPatterns<C> taps;
+    taps.build(valid ? x : x0, W, ft.sx0, ft.mis0, a.kxw);
+    uint32_t wa = (uint32_t)(wave * ROWD) * 4u + (uint32_t)taps.A;   // window address, current frame
     uint32_t half = 32768u;
     float var_max_v = a.k.var_max;   // (the clamp takes one scalar operand, var_min)
     asm volatile("" : "+v"(half), "+v"(var_max_v));   // kept in registers, not re-materialised per use
@@ -903,46 +982,15 @@ __global__ __launch_bounds__(256) void mog2_frames_kernel(const Mog2FramesArgs a
 
     __syncthreads();   // the only barrier: every tile is in LDS
 
-    // blurred pixel of the current frame: 3 x 3 aligned dwords from LDS, horizontal
-    // pass as v_dot4_u32_u8 against the lane's tap patterns, vertical pass as 24-bit
-    // multiply-adds onto the rounding constant, >> 16: the same integer as
-    // mog2_kernel's fused front end (sums of the same products, no intermediate
-    // rounding), which is the separable 8.8 blur of blur_kernel
+    // blurred pixel of the current frame as floats (batch: the nine LDS reads issued
+    // back to back -- not in the general loop, which has the whole mixture in registers)
     auto frame_input = [&](float (&xin)[C], bool batch) {
-        uint32_t win[3][3];
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-            const uint32_t *q = (const uint32_t *)((const char *)tiles + wa + (uint32_t)(j * ROWD) * 4u);
-#pragma unroll
-            for (int i = 0; i < 3; i++)
-                win[j][i] = q[i];
-        }
+        uint32_t v[C];
+        taps.template blur<ROWD>(tiles, wa, ky, half, batch, v);
         wa += (uint32_t)TILE * 4u;   // next frame
-        // keeps all nine live at one point: the reads are issued back to back (not in
-        // the general loop, which has the whole mixture in registers)
-        if (batch)
-            asm volatile(""
-                         : "+v"(win[0][0]), "+v"(win[0][1]), "+v"(win[0][2]), "+v"(win[1][0]),
-                           "+v"(win[1][1]), "+v"(win[1][2]), "+v"(win[2][0]), "+v"(win[2][1]),
-                           "+v"(win[2][2]));
 #pragma unroll
-        for (int c = 0; c < C; c++) {
-            uint32_t acc = half;   // 2^15 in a VGPR: the multiply-add takes one scalar operand
-#pragma unroll
-            for (int j = 0; j < 3; j++) {
-                uint32_t h = __builtin_amdgcn_udot4(win[j][0], pat[c][0], 0u, false);
-                h = __builtin_amdgcn_udot4(win[j][1], pat[c][1], h, false);
-                h = __builtin_amdgcn_udot4(win[j][2], pat[c][2], h, false);
-                // acc += ky[j] * h as ONE v_mad_u32_u24 (h < 2^16, ky < 2^10).  The empty
-                // asm pins the running sum: without it the three products are
-                // re-associated into multiply, multiply-add, multiply, three-way add.
-                // (The multiply-add itself must stay compiler-generated: a VALU read of
-                // a v_dot4 result needs wait states that only the compiler inserts.)
-                acc = __umul24(ky[j], h) + acc;
-                asm volatile("" : "+v"(acc));
-            }
-            xin[c] = (float)(acc >> 16);
-        }
+        for (int c = 0; c < C; c++)
+            xin[c] = (float)v[c];
     };
     // The frame's scalars: one 32-byte scalar load from the argument segment,
     // requested one frame ahead (the record of frame ti + 1 travels while frame ti
@@ -1053,6 +1101,102 @@ __global__ __launch_bounds__(256) void mog2_frames_kernel(const Mog2FramesArgs a
     }
     if (nm_dirty)
         a.modes[rowoff + xl] = (uint8_t)nmodes;
+}
+
+// ---------------------------------------------------------------------------
+// fd_frames_kernel: GaussianBlur 3x3 + FrameDifferencing.apply [REF pipeline.py:
+// 463-470, segmentation.py:40-70] for T consecutive frames of every stream in one
+// launch, on the staging / tap-pattern front end of mog2_frames_kernel.  The
+// blurred frame never exists in memory: the lane keeps its blurred pixel of frame
+// t - 1 in registers, and only the last one of the launch is written out (C bytes
+// per pixel) for the next launch to start from.  Per pixel and frame: C bytes in,
+// one mask byte out, 2 C / T for the hand-over -- against 6 C + 1 + 6 C for the
+// separate blur, difference and copy-of-the-previous-frame kernels.
+// ---------------------------------------------------------------------------
+struct FdFramesArgs {
+    const uint8_t *frame;
+    uint8_t *mask;
+    // the blurred last frame of the previous launch (if has_prev) / of this launch:
+    // one dword per pixel, channel c in byte c (the kernels' own hand-over format)
+    const uint32_t *prev_in;
+    uint32_t *prev_out;
+    uint8_t *rowflags;        // as Mog2FramesArgs::rowflags (or NULL)
+    size_t frame_stride, mask_stride;
+    int H, W, T, has_prev, ithr, flag_pitch;
+    uint32_t kxw, ky012;
+};
+
+template <int C, int NT>   // NT: frames staged per launch (1 for the per-frame call, else kMaxT)
+__global__ __launch_bounds__(256) void fd_frames_kernel(const FdFramesArgs a)
+{
+    typedef FrameTiles<C, NT> Tiles;
+    constexpr int ROWD = Tiles::ROWD, TILE = Tiles::TILE;
+    __shared__ uint32_t tiles[Tiles::LDS_DWORDS];
+
+    const int H = a.H, W = a.W, T = a.T;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    const int img = blockIdx.z;
+    const int x = x0 + lane, y = y0 + wave;
+    const size_t N = (size_t)H * W;
+
+    Tiles ft;
+    uint32_t raw[NT][2][Tiles::NDW];
+    ft.load(a.frame, a.frame_stride, H, W, T, img, x0, y0, wave, lane, raw);
+
+    // a lane outside the image shadows a pixel inside it; only its stores are masked
+    const bool valid = y < H && x < W;
+    const unsigned xl = valid ? (unsigned)x : 0u;
+    const size_t pix = (size_t)img * N + (size_t)(y < H ? y : 0) * W + xl;
+    const uint32_t prev_px = a.has_prev ? a.prev_in[pix] : 0u;
+    uint32_t prev[C];
+#pragma unroll
+    for (int c = 0; c < C; c++)
+        prev[c] = (prev_px >> (8 * c)) & 255u;
+
+    Tiles::store(tiles, wave, lane, raw);
+    TapPatterns<C> taps;
+    taps.build(valid ? x : x0, W, ft.sx0, ft.mis0, a.kxw);
+    uint32_t wa = (uint32_t)(wave * ROWD) * 4u + (uint32_t)taps.A;
+    uint32_t half = 32768u;
+    asm volatile("" : "+v"(half));
+    const uint32_t ky[3] = {a.ky012 & 1023u, (a.ky012 >> 10) & 1023u, a.ky012 >> 20};
+    __syncthreads();
+
+    uint8_t *mp = a.mask + pix;
+    bool have = a.has_prev != 0;   // the first frame ever gives an all-zero mask
+    uint32_t nz = 0;
+    for (int ti = 0; ti < T; ti++) {
+        uint32_t v[C];
+        taps.template blur<ROWD>(tiles, wa, ky, half, true, v);
+        wa += (uint32_t)TILE * 4u;
+        // |X - prev| > floor(thr) -> 255 per channel; np.mean(..., dtype=uint8): the
+        // channel sum wraps in uint8, then / C truncated (fd_kernel's statements)
+        unsigned acc = 0;
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const int d = (int)v[c] > (int)prev[c] ? (int)v[c] - (int)prev[c] : (int)prev[c] - (int)v[c];
+            acc += d > a.ithr ? 255u : 0u;
+            prev[c] = v[c];
+        }
+        acc &= 255u;
+        const uint8_t out = have ? (uint8_t)(acc / (unsigned)C) : (uint8_t)0;
+        have = true;
+        nz |= (__builtin_amdgcn_ballot_w64(out != 0) != 0 ? 1u : 0u) << ti;
+        if (valid)
+            *mp = out;
+        mp += a.mask_stride;
+    }
+    if (a.rowflags != nullptr && y < H && lane == 0)
+        a.rowflags[((size_t)img * H + y) * a.flag_pitch + blockIdx.x] = (uint8_t)nz;
+    if (valid) {
+        uint32_t px = 0;
+#pragma unroll
+        for (int c = 0; c < C; c++)
+            px |= prev[c] << (8 * c);
+        a.prev_out[pix] = px;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1917,6 +2061,57 @@ hipError_t fd_apply(const uint8_t *cur, const uint8_t *prev, bool has_prev, int 
     case 4: hipLaunchKernelGGL(fd_kernel<4>, g, dim3(256), 0, s, cur, prev, (int)has_prev, ithr, mask, npix); break;
     default: return hipErrorInvalidValue;
     }
+    return hipGetLastError();
+}
+
+bool fd_frames_supported(const uint8_t *frame, int n_img, int h, int w, int c, const Taps &t)
+{
+    // byte taps whose folded outer pair fits a byte, at least two columns, and every
+    // staged row of every frame at the same offset mod 4 (see mog2_apply)
+    return t.nkx == 3 && t.nky == 3 && t.box_scale == 0.0 && t.kx[0] < 256 && t.kx[1] < 256 &&
+           t.kx[2] < 256 && t.kx[0] + t.kx[2] <= 255 && w > 1 && ((size_t)w * c) % 4 == 0 &&
+           ((size_t)h * w * c) % 4 == 0 && ((size_t)n_img * h * w * c) % 4 == 0 &&
+           (uintptr_t)frame % 4 == 0 && (c == 1 || c == 3 || c == 4);
+}
+
+hipError_t fd_frames_apply(const uint8_t *frame, uint8_t *mask, const uint32_t *prev_in,
+                           uint32_t *prev_out, bool has_prev, int ithr, int n_img, int h, int w, int c,
+                           int T, const Taps &t, hipStream_t s, uint8_t *rowflags)
+{
+    if (n_img < 1 || h < 1 || (h + TH - 1) / TH > 65535 || n_img > 65535 || T < 1 || T > kMaxT ||
+        !fd_frames_supported(frame, n_img, h, w, c, t) || !prev_out || (has_prev && !prev_in))
+        return hipErrorInvalidValue;
+    FdFramesArgs a;
+    a.frame = frame;
+    a.mask = mask;
+    a.prev_in = prev_in;
+    a.prev_out = prev_out;
+    a.rowflags = rowflags;
+    a.frame_stride = (size_t)n_img * h * w * c;
+    a.mask_stride = (size_t)n_img * h * w;
+    a.H = h;
+    a.W = w;
+    a.T = T;
+    a.has_prev = has_prev ? 1 : 0;
+    a.ithr = ithr;
+    a.flag_pitch = rowflag_pitch(w);
+    a.kxw = (uint32_t)t.kx[0] | ((uint32_t)t.kx[1] << 8) | ((uint32_t)t.kx[2] << 16);
+    a.ky012 = t.ky[0] | (t.ky[1] << 10) | (t.ky[2] << 20);
+    dim3 g = grid3(w, h, n_img, TW, TH);
+#define GOF_LAUNCH_FD(CC)                                                                   \
+    do {                                                                                    \
+        if (T == 1)                                                                         \
+            hipLaunchKernelGGL((fd_frames_kernel<CC, 1>), g, dim3(256), 0, s, a);           \
+        else                                                                                \
+            hipLaunchKernelGGL((fd_frames_kernel<CC, kMaxT>), g, dim3(256), 0, s, a);       \
+    } while (0)
+    switch (c) {
+    case 1: GOF_LAUNCH_FD(1); break;
+    case 3: GOF_LAUNCH_FD(3); break;
+    case 4: GOF_LAUNCH_FD(4); break;
+    default: return hipErrorInvalidValue;
+    }
+#undef GOF_LAUNCH_FD
     return hipGetLastError();
 }
 

@@ -442,6 +442,32 @@ def test_morphology_skips_only_empty_regions(oracle, T):
     assert empty > 0   # the scene did contain empty strips-worth of mask
 
 
+@pytest.mark.parametrize("shape", [(46, 76, 3), (30, 68, 1), (22, 66, 4), (37, 130, 3)])
+def test_fd_fused_kernel(oracle, shape):
+    """GaussianBlur + FrameDifferencing as one multi-frame kernel (aligned frames: the
+    first three shapes) and as separate kernels (130 * 3 is not a multiple of 4):
+    one-frame calls, full and partial launches, two streams; the first mask ever is
+    all zero [REF tests/test_segmentation.py:19], every later one equals the oracle's
+    blur -> FD -> erode -> dilate."""
+    from pygofpid_amd.foreground import ForegroundPipeline
+    h, w, c = shape
+    S = 2
+    clips = [Clip(h, w, c, seed=700 + s, n_objects=2, speed=4) for s in range(S)]
+    gpu = ForegroundPipeline((h, w, c), streams=S, detector="FD", fd_threshold=6)
+    refs = [oracle.Pipeline(h, w, c, detector="FD", fd_thr=6) for _ in range(S)]
+    t = 0
+    for T in (1, 1, 8, 3, 11, 1):
+        frames = np.stack([np.stack([cl.frame(t + i) for cl in clips]) for i in range(T)])
+        got = gpu.apply_many(frames).reshape(T, S, h, w)
+        for i in range(T):
+            for s in range(S):
+                want = refs[s].apply(frames[i, s])
+                if t + i == 0:
+                    assert not want.any()
+                assert np.array_equal(got[i, s], want), (shape, t + i, s, int((got[i, s] != want).sum()))
+        t += T
+
+
 def test_pipeline_temporal_blocking_other_paths(oracle):
     """apply_many through the unfused blur, the FD detector and a grey stream."""
     from pygofpid_amd.foreground import ForegroundPipeline
