@@ -50,3 +50,25 @@ def test_fuzz_fused_path(oracle, cfg):
                 want = refs[s].apply(frames[k, s])
                 assert np.array_equal(got[k, s], want), (cfg, t + k, s, int((got[k, s] != want).sum()))
         t += T
+
+
+def _aligned_configs(n, seed):
+    """Dword-aligned rows (the multi-frame MOG2 / FD kernels and the morphology's
+    zero-region skipping), more frames per call, several launch chunks."""
+    rng = np.random.default_rng(seed)
+    for i in range(n):
+        c = int(rng.choice([1, 3, 3, 4]))
+        w = int(rng.integers(1, 90)) * 4
+        h = int(rng.integers(1, 120))
+        streams = int(rng.choice([1, 2, 3]))
+        T = int(rng.choice([2, 3, 7, 8, 9, 12, 17]))
+        blur = ("gauss", 3, float(rng.choice([4.0, 0.0, 1.2])))
+        det = "MOG2" if rng.random() < 0.6 else "FD"
+        nm = int(rng.integers(0, 3))
+        morph = [(str(rng.choice(["erode", "dilate"])), int(rng.choice([3, 5, 7]))) for _ in range(nm)]
+        yield 1000 + i, h, w, c, streams, T, blur, det, morph
+
+
+@pytest.mark.parametrize("cfg", list(_aligned_configs(80, seed=777)), ids=lambda c: "cfg%d" % c[0])
+def test_fuzz_multi_frame_kernels(oracle, cfg):
+    test_fuzz_fused_path(oracle, cfg)
