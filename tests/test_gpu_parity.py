@@ -555,6 +555,43 @@ def test_pipeline_4k_open_close_bit_exact(oracle):
     _run_pair(gpu, ref, Clip(h, w, c, seed=3).frames(3))
 
 
+def test_pipeline_full_hd_multi_frame(oracle):
+    """The benchmark's own form at its own geometry: 1080p, 8 frames per launch,
+    two streams, three launches; every mask and the final model state against the
+    frame-by-frame oracle (multi-frame kernel, row flags, skipping morphology)."""
+    from pygofpid_amd.foreground import ForegroundPipeline
+    h, w, c, S, T = 1080, 1920, 3, 2, 8
+    clips = [Clip(h, w, c, seed=40 + s, n_objects=4) for s in range(S)]
+    gpu = ForegroundPipeline((h, w, c), streams=S)
+    refs = [oracle.Pipeline(h, w, c) for _ in range(S)]
+    for r in range(3):
+        frames = np.stack([np.stack([cl.frame(T * r + i) for cl in clips]) for i in range(T)])
+        got = gpu.apply_many(frames)
+        for i in range(T):
+            for s in range(S):
+                want = refs[s].apply(frames[i, s])
+                assert np.array_equal(got[i, s], want), (T * r + i, s, int((got[i, s] != want).sum()))
+    st = gpu.mog2_state()
+    n = h * w
+    for s in range(S):
+        got = {"modes": st["modes"][s * n:(s + 1) * n], "weight": st["weight"][:, s * n:(s + 1) * n],
+               "var": st["var"][:, s * n:(s + 1) * n], "mean": st["mean"][:, :, s * n:(s + 1) * n]}
+        _assert_state_equal(got, refs[s].export())
+
+
+def test_pipeline_4k_open_close_multi_frame(oracle):
+    """BASELINE config 3 geometry through an 8-frame launch and the 7x7 open / close chain."""
+    from pygofpid_amd.foreground import ForegroundPipeline
+    h, w, c = 2160, 3840, 3
+    k7 = np.ones((7, 7), np.uint8)
+    gpu = ForegroundPipeline((h, w, c), morph=[("erode", k7), ("dilate", k7), ("dilate", k7), ("erode", k7)])
+    ref = oracle.Pipeline(h, w, c, morph=(("erode", 7), ("dilate", 7), ("dilate", 7), ("erode", 7)))
+    frames = np.stack(Clip(h, w, c, seed=5, n_objects=3).frames(8))
+    got = gpu.apply_many(frames)
+    for i in range(8):
+        assert np.array_equal(got[i], ref.apply(frames[i])), i
+
+
 def test_pipeline_errors():
     from pygofpid_amd.foreground import ForegroundPipeline
     with pytest.raises(ValueError):
