@@ -16,6 +16,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <new>
 #include <vector>
 
 #include "gofpid_hip.h"
@@ -45,10 +46,78 @@ extern "C" int gof_find_external_contours(const uint8_t *mask, int h, int w, int
     *offsets = nullptr;
     *n_contours = 0;
     const int W = w + 2, H = h + 2;   // one-pixel frame of zeros, as cv2 assumes
-    std::vector<int32_t> f((size_t)W * H, 0);
-    for (int y = 0; y < h; y++)
-        for (int x = 0; x < w; x++)
-            f[(size_t)(y + 1) * W + x + 1] = mask[(size_t)y * w + x] ? 1 : 0;
+    // A foreground mask is mostly zeros.  The label image is a per-thread buffer
+    // that is all zero between calls (only the labels of non-zero mask bytes are
+    // ever written, and they are cleared again on the way out), only non-zero mask
+    // bytes are transcribed, and both passes skip zeros eight bytes at a time on
+    // the mask itself: a label is non-zero exactly where the mask is, whatever sign
+    // or magnitude the border following gives it.
+    static thread_local std::vector<int32_t> label_buf;
+    if (label_buf.size() < (size_t)W * H) {
+        try {
+            label_buf.assign((size_t)W * H, 0);
+        } catch (const std::bad_alloc &) {
+            return GOF_ENOMEM;
+        }
+    }
+    int32_t *const f = label_buf.data();
+    std::vector<uint8_t> row_any((size_t)h, 0);
+    struct Cleaner {   // labels back to zero, whichever way the function is left
+        const uint8_t *mask;
+        int32_t *f;
+        const uint8_t *row_any;
+        int h, w, W;
+        ~Cleaner()
+        {
+            for (int y = 0; y < h; y++) {
+                if (!row_any[y])
+                    continue;
+                const uint8_t *r = mask + (size_t)y * w;
+                int32_t *fr = f + (size_t)(y + 1) * W + 1;
+                int x = 0;
+                for (; x + 8 <= w; x += 8) {
+                    uint64_t v;
+                    memcpy(&v, r + x, 8);
+                    if (!v)
+                        continue;
+                    for (int k = 0; k < 8; k++)
+                        fr[x + k] = 0;
+                }
+                for (; x < w; x++)
+                    fr[x] = 0;
+            }
+        }
+    } cleaner{mask, f, row_any.data(), h, w, W};
+    for (int y = 0; y < h; y++) {
+        const uint8_t *r = mask + (size_t)y * w;
+        int32_t *fr = f + (size_t)(y + 1) * W + 1;
+        bool any = false;
+        int x = 0;
+        for (; x + 8 <= w; x += 8) {
+            if (x + 32 <= w) {   // thirty-two zeros at once
+                uint64_t q[4];
+                memcpy(q, r + x, 32);
+                if (!(q[0] | q[1] | q[2] | q[3])) {
+                    x += 24;
+                    continue;
+                }
+            }
+            uint64_t v;
+            memcpy(&v, r + x, 8);
+            if (!v)
+                continue;
+            any = true;
+            for (int k = 0; k < 8; k++)
+                if (r[x + k])
+                    fr[x + k] = 1;
+        }
+        for (; x < w; x++)
+            if (r[x]) {
+                any = true;
+                fr[x] = 1;
+            }
+        row_any[(size_t)y] = any;
+    }
 
     std::vector<int32_t> pts;             // x, y pairs of every returned contour
     std::vector<int32_t> offs(1, 0);
@@ -58,11 +127,23 @@ extern "C" int gof_find_external_contours(const uint8_t *mask, int h, int w, int
     int nbd = 1;
 
     for (int i = 1; i < H - 1; i++) {
+        if (!row_any[(size_t)(i - 1)])
+            continue;
         int lnbd = 1;
+        const uint8_t *r = mask + (size_t)(i - 1) * w;
         for (int j = 1; j < W - 1; j++) {
-            const int32_t fij = f[(size_t)i * W + j];
-            if (fij == 0)
+            const int x = j - 1;
+            if ((x & 7) == 0 && x + 8 <= w) {   // eight zeros at once
+                uint64_t v;
+                memcpy(&v, r + x, 8);
+                if (!v) {
+                    j += 7;
+                    continue;
+                }
+            }
+            if (r[x] == 0)
                 continue;
+            const int32_t fij = f[(size_t)i * W + j];
             int i2 = 0, j2 = 0;
             bool outer = false, start = false;
             if (fij == 1 && f[(size_t)i * W + j - 1] == 0) {
