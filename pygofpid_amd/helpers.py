@@ -31,6 +31,15 @@ def get_center(contour, dtype=np.int16):
     return np.array([x, int(m["m01"] / m["m00"])], dtype=dtype)
 
 
+def get_bottom_and_center(contour, dtype=np.int16):
+    """(get_bottom(contour), get_center(contour)) from one evaluation of the moments
+    (the reference computes them once per call, pipeline.py:575-576: same values)."""
+    m, x = _centroid_x(contour)
+    bottom = np.array([x, np.max(np.asarray(contour)[..., 1])], dtype=dtype)
+    center = np.array([x, int(m["m01"] / m["m00"])], dtype=dtype)
+    return bottom, center
+
+
 def normalize_coords(coords, shape, dtype=np.float64):
     """Pixel (x, y) -> fractions of (width, height)."""
     out = np.array(coords, dtype=dtype)

@@ -44,13 +44,29 @@ def _xy(contour):
     return c.reshape(-1, 2).astype(np.float64)
 
 
+def _next(v):
+    """np.roll(v, -1) without its generic machinery (these run per blob and frame)."""
+    out = np.empty_like(v)
+    out[:-1] = v[1:]
+    out[-1] = v[0]
+    return out
+
+
+def _prev(v):
+    """np.roll(v, 1)"""
+    out = np.empty_like(v)
+    out[1:] = v[:-1]
+    out[0] = v[-1]
+    return out
+
+
 def contourArea(contour):
     """|shoelace| / 2 (cv.contourArea, oriented=False)."""
     p = _xy(contour)
     if len(p) < 3:
         return 0.0
     x, y = p[:, 0], p[:, 1]
-    return abs(float(np.dot(x, np.roll(y, -1)) - np.dot(np.roll(x, -1), y))) * 0.5
+    return abs(float(np.dot(x, _next(y)) - np.dot(_next(x), y))) * 0.5
 
 
 def moments(contour):
@@ -59,7 +75,7 @@ def moments(contour):
     p = _xy(contour)
     if len(p) == 0:
         return {"m00": 0.0, "m10": 0.0, "m01": 0.0}
-    x0, y0 = np.roll(p[:, 0], 1), np.roll(p[:, 1], 1)   # previous vertex
+    x0, y0 = _prev(p[:, 0]), _prev(p[:, 1])   # previous vertex
     x1, y1 = p[:, 0], p[:, 1]
     cross = x0 * y1 - x1 * y0
     a00 = cross.sum()

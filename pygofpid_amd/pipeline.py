@@ -26,8 +26,8 @@ import numpy as np
 
 from . import cv, hostcv
 from .foreground import ForegroundPipeline
-from .helpers import (SimpleLinearRegression, find_contours, get_bottom, get_center,
-                      unnormalize_coords)
+from .helpers import (SimpleLinearRegression, find_contours, get_bottom, get_bottom_and_center,
+                      get_center, unnormalize_coords)
 from .segmentation import FrameDifferencing
 
 _DEFAULT_BLUR = {'fun': cv.GaussianBlur, 'ksize': (3, 3), 'borderType': cv.BORDER_DEFAULT}
@@ -246,8 +246,7 @@ class GOFPID():
         self.blobs_ = [self._create_blob(c) for c in contours]
 
     def _create_blob(self, contour):
-        bottom = get_bottom(contour, dtype=np.int16)
-        center = get_center(contour, dtype=np.int16)
+        bottom, center = get_bottom_and_center(contour, dtype=np.int16)
         anchor = bottom if self.post_filter['anchor'] == 'bottom' else center
         return {'contour': contour, 'anchor': anchor, 'bottom': bottom, 'center': center}
 
