@@ -227,7 +227,10 @@ gofk::Mog2Consts next_consts(gof_mog2 *m, int T)
         const float weight1 = a1 * 1.f + pr;
         const float wfit1 = weight1 + aT;
         const float tfit = 0.f + wfit1, tmiss = 0.f + weight1;
-        const bool ok = m->p.var_min <= m->p.var_max && std::isnormal(wfit1) && std::isnormal(weight1) && !(wfit1 < -pr) &&
+        // (the settled path orders Tg / Tb / TB by their bit patterns: finite values only)
+        const bool ok = std::isfinite(m->p.var_threshold) && std::isfinite(m->p.var_threshold_gen) &&
+                        std::isfinite(m->p.background_ratio) && std::isfinite(m->p.var_init) &&
+                        m->p.var_min <= m->p.var_max && std::isnormal(wfit1) && std::isnormal(weight1) && !(wfit1 < -pr) &&
                         !(weight1 < -pr) && std::fabs(tfit) > FLT_EPSILON &&
                         std::fabs(tmiss) > FLT_EPSILON;
         gofk::FrameRates &f = k.fr[i];
