@@ -1,8 +1,18 @@
 // gfx950 (MI355X, CDNA4) kernels of the foreground path.  Written for wave64,
 // 256-thread workgroups, SoA model planes read and written as fully coalesced
-// 256-B wave segments.  All of these are HBM-bound stencils / per-pixel state
-// machines: no MFMA (north_star), the work is coalescing, LDS staging and
-// keeping the per-pixel model in registers.
+// 256-B wave segments.  All of these are byte / per-pixel state-machine stencils:
+// no MFMA (north_star), the work is coalescing, LDS staging, keeping the per-pixel
+// model in registers and, once that has taken the memory out of the way, the
+// number of instructions a wave issues.
+//
+//   mog2_kernel          blur 3x3 + MOG2, one frame per launch (and every layout the
+//                        fast paths do not cover)
+//   mog2_frames_kernel   the same for up to 8 frames per launch (FrameTiles,
+//                        TapPatterns, settled-wave loop)
+//   fd_frames_kernel     blur 3x3 + frame differencing on the same front end
+//   blur_kernel, fd_kernel, gray_kernel   the unfused steps
+//   morph_stream_bits_kernel / morph_stream_kernel / morph_chain_kernel / morph_kernel
+//                        erode / dilate chains (registers + DPP, LDS, any SE)
 //
 // Compiled with -ffp-contract=off: the MOG2 update must round after every
 // multiply and add exactly like the scalar C++ it restates; the
