@@ -35,6 +35,7 @@ if ROOT not in sys.path:
 os.environ.setdefault("OMP_WAIT_POLICY", "active")
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+EVENT_STRIDE = 4     # timed steps between two event-bracketed ones
 
 
 def make_pool(torch, streams, pool, h, w, device, seed, n_objects=6):
@@ -187,7 +188,9 @@ def main():
     barrier()
     mbar_start = pipe.mean_modes()
     if not args.no_events:
-        pipe.profile(True, K)
+        # HIP events around the kernels of every EVENT_STRIDE-th timed step (each record
+        # costs the stream a few microseconds; a sample keeps that off `value`)
+        pipe.profile(True, K, stride=EVENT_STRIDE)
     barrier()
     if os.environ.get("GOF_ABLATE_TIMED"):          # profiles/ ablations: flip after the warm-up
         os.environ["GOF_ABLATE"] = os.environ["GOF_ABLATE_TIMED"]

@@ -211,6 +211,9 @@ void gof_free(void *p);
  * synchronises the recorded events and returns the SUM of elapsed ms and the
  * number of applies measured, then clears the record. */
 int gof_pipeline_profile_enable(gof_pipeline *p, int enable, int capacity);
+/* Bracket only every stride-th apply (stride >= 1, default 1): a sample over the
+ * timed region that costs the stream fewer event records. */
+int gof_pipeline_profile_stride(gof_pipeline *p, int stride);
 int gof_pipeline_profile_query(gof_pipeline *p, double *detector_ms, double *morph_ms,
                                int *n_applies);
 

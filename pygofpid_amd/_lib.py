@@ -112,12 +112,34 @@ SIGNATURES = {
                                              C.POINTER(C.c_int)]),
     "gof_free": (None, [C.c_void_p]),
     "gof_pipeline_profile_enable": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "gof_pipeline_profile_stride": (C.c_int, [C.c_void_p, C.c_int]),
     "gof_pipeline_profile_query": (C.c_int, [C.c_void_p, C.POINTER(C.c_double),
                                              C.POINTER(C.c_double), C.POINTER(C.c_int)]),
 }
 
 _lib = None
 _lock = threading.Lock()
+
+
+def _adopt_torch_hip_runtime():
+    """One process, one HIP runtime.  A PyTorch-ROCm wheel carries its own
+    libamdhip64; if this library pulled in the system copy first, a later
+    `import torch` would meet a second runtime and find no GPU.  So when torch is
+    installed (whether or not it has been imported yet) its copy is loaded first
+    and libgofpid_hip.so binds to it.  Without torch the system runtime is used."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        try:
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
 
 
 def load():
@@ -130,6 +152,7 @@ def load():
                     "pygofpid_amd: %s is not built (run `python -c 'import __graft_entry__ as g; "
                     "g.build()'` or `make -C pygofpid_amd/csrc`); there is no CPU fallback"
                     % LIB_PATH)
+            _adopt_torch_hip_runtime()
             lib = C.CDLL(LIB_PATH)
             for name, (res, args) in SIGNATURES.items():
                 fn = getattr(lib, name)

@@ -130,6 +130,8 @@ struct gof_pipeline {
     bool prof = false;
     std::vector<hipEvent_t> events;
     size_t prof_used = 0;
+    int prof_stride = 1;       // bracket every prof_stride-th apply
+    size_t prof_seen = 0;      // applies since profiling was enabled
 };
 
 namespace {
@@ -992,7 +994,8 @@ int gof_pipeline_apply_dev_many(gof_pipeline *p, const void *d_frames, void *d_m
         x = (const uint8_t *)p->blurred.p;
     }
 
-    const bool prof = p->prof && 3 * (p->prof_used + 1) <= p->events.size();
+    const bool prof = p->prof && (p->prof_seen++ % (size_t)p->prof_stride) == 0 &&
+                      3 * (p->prof_used + 1) <= p->events.size();
     hipEvent_t *ev = prof ? &p->events[3 * p->prof_used] : nullptr;
     if (prof)
         GOF_HIP(hipEventRecord(ev[0], s));
@@ -1129,11 +1132,20 @@ int gof_pipeline_profile_enable(gof_pipeline *p, int enable, int capacity)
     GOF_HIP(hipSetDevice(p->ctx->device));
     p->prof = enable != 0;
     p->prof_used = 0;
+    p->prof_seen = 0;
     while (p->prof && p->events.size() < 3 * (size_t)capacity) {
         hipEvent_t e;
         GOF_HIP(hipEventCreate(&e));
         p->events.push_back(e);
     }
+    return GOF_OK;
+}
+
+int gof_pipeline_profile_stride(gof_pipeline *p, int stride)
+{
+    if (!p || stride < 1)
+        return fail(GOF_EINVAL, "bad argument");
+    p->prof_stride = stride;
     return GOF_OK;
 }
 

@@ -133,8 +133,10 @@ class ForegroundPipeline:
                                                               C.byref(k)))
         return t.value, k.value
 
-    def profile(self, enable, capacity=0):
-        """Bracket each step's kernels with HIP events on the launch stream."""
+    def profile(self, enable, capacity=0, stride=1):
+        """Bracket each step's kernels (every stride-th step's) with HIP events on the
+        launch stream."""
+        _lib.check(_lib.load().gof_pipeline_profile_stride(self._h, int(stride)))
         _lib.check(_lib.load().gof_pipeline_profile_enable(self._h, int(bool(enable)),
                                                            int(capacity)))
 
