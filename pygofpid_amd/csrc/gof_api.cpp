@@ -657,6 +657,8 @@ int gof_mog2_export(gof_mog2 *m, float *weight, float *var, float *mean, uint8_t
     }
     GOF_HIP(hipMemcpyAsync(modes, m->view().modes, n, hipMemcpyDeviceToHost, s));
     GOF_HIP(hipStreamSynchronize(s));
+    for (size_t i = 0; i < n; i++)   // bit 7 is the kernels' "first weight is 1.0f" note
+        modes[i] &= 0x7f;
     return GOF_OK;
 }
 

@@ -50,6 +50,10 @@ __device__ __forceinline__ int reflect101(int p, int len)
 
 constexpr int TW = 64;
 constexpr int TH = 4;
+// the byte of the mode-count plane: count in the low bits, kW0One = "the first mode's
+// weight is exactly 1.0f" (kept true by every kernel that writes the byte; a byte
+// without the bit only costs a read of the weight plane)
+constexpr int kModeCount = 0x7f, kW0One = 0x80;
 
 template <int C>
 struct PixelModel {
@@ -517,14 +521,19 @@ __global__ __launch_bounds__(256, (!MULTI && ALN && C <= 3) ? 8 : 1) void mog2_k
     const size_t rowoff = (size_t)img * N + (size_t)yy * W; // wave-uniform
     float *const prow = planes + rowoff;
     PixelModel<C> M;
-    int nmodes = valid ? (int)modes[rowoff + xl] : 0;
-    const int nmodes_in = nmodes;
-    M.w[0] = prow[xl];
-    const uint32_t w0_in = __float_as_uint(M.w[0]);
+    // the mode-count byte also says (bit 7, kW0One) that the first mode's weight is
+    // exactly 1.0f -- the settled state of most pixels -- so that a wave whose pixels
+    // all say so does not read the weight plane at all
+    const int mbyte_in = valid ? (int)modes[rowoff + xl] : 0;
+    int nmodes = mbyte_in & kModeCount;
     M.var[0] = (prow + np)[xl];
 #pragma unroll
     for (int c = 0; c < C; c++)
         M.mu[0][c] = (prow + (size_t)(2 + c) * np)[xl];
+    M.w[0] = 1.f;
+    if (__builtin_amdgcn_ballot_w64(valid && !(mbyte_in & kW0One)) != 0)
+        M.w[0] = prow[xl];
+    const uint32_t w0_in = __float_as_uint(M.w[0]);
     // remaining modes only if some pixel of the wave has one (wave-uniform split)
     if (__builtin_amdgcn_ballot_w64(nmodes > 1) != 0) {
 #pragma unroll
@@ -705,7 +714,8 @@ __global__ __launch_bounds__(256, (!MULTI && ALN && C <= 3) ? 8 : 1) void mog2_k
     // weight of a settled single-mode pixel renormalises to exactly 1.0f frame
     // after frame, and the mode count rarely changes.
     const bool w0_dirty = __builtin_amdgcn_ballot_w64(nmodes > 0 && __float_as_uint(M.w[0]) != w0_in) != 0;
-    const bool nm_dirty = __builtin_amdgcn_ballot_w64(nmodes != nmodes_in) != 0;
+    const int mbyte = nmodes | ((nmodes > 0 && __float_as_uint(M.w[0]) == 0x3f800000u) ? kW0One : 0);
+    const bool nm_dirty = __builtin_amdgcn_ballot_w64(mbyte != mbyte_in) != 0;
 #pragma unroll
     for (int m = 0; m < kMaxModes; m++) {
         if (m < nmodes) {
@@ -719,7 +729,7 @@ __global__ __launch_bounds__(256, (!MULTI && ALN && C <= 3) ? 8 : 1) void mog2_k
         }
     }
     if (nm_dirty)
-        modes[rowoff + xl] = (uint8_t)nmodes;
+        modes[rowoff + xl] = (uint8_t)mbyte;
 }
 
 // ---------------------------------------------------------------------------
@@ -941,14 +951,16 @@ __global__ __launch_bounds__(256) void mog2_frames_kernel(const Mog2FramesArgs a
     float *const prow = a.planes + rowoff;
     const size_t np = a.np;
     PixelModel<C> M;
-    int nmodes = (int)a.modes[rowoff + xl];
-    const int nmodes_in = nmodes;
-    M.w[0] = prow[xl];
-    const uint32_t w0_in = __float_as_uint(M.w[0]);
+    const int mbyte_in = (int)a.modes[rowoff + xl];   // mode count | kW0One (see mog2_kernel)
+    int nmodes = mbyte_in & kModeCount;
     M.var[0] = (prow + np)[xl];
 #pragma unroll
     for (int c = 0; c < C; c++)
         M.mu[0][c] = (prow + (size_t)(2 + c) * np)[xl];
+    M.w[0] = 1.f;
+    if (__builtin_amdgcn_ballot_w64(!(mbyte_in & kW0One)) != 0)
+        M.w[0] = prow[xl];
+    const uint32_t w0_in = __float_as_uint(M.w[0]);
     // slots 1.. are loaded only if some pixel of the wave has them; otherwise slot 1
     // starts empty (the single-mode loops may fill it) and slots 2.. stay untouched
     // until the general loop is entered
@@ -1096,7 +1108,8 @@ __global__ __launch_bounds__(256) void mog2_frames_kernel(const Mog2FramesArgs a
 
     // planes no pixel of the wave changed are not written back (see mog2_kernel)
     const bool w0_dirty = __builtin_amdgcn_ballot_w64(nmodes > 0 && __float_as_uint(M.w[0]) != w0_in) != 0;
-    const bool nm_dirty = __builtin_amdgcn_ballot_w64(nmodes != nmodes_in) != 0;
+    const int mbyte = nmodes | ((nmodes > 0 && __float_as_uint(M.w[0]) == 0x3f800000u) ? kW0One : 0);
+    const bool nm_dirty = __builtin_amdgcn_ballot_w64(mbyte != mbyte_in) != 0;
 #pragma unroll
     for (int m = 0; m < kMaxModes; m++) {
         if (m < nmodes) {
@@ -1110,7 +1123,7 @@ __global__ __launch_bounds__(256) void mog2_frames_kernel(const Mog2FramesArgs a
         }
     }
     if (nm_dirty)
-        a.modes[rowoff + xl] = (uint8_t)nmodes;
+        a.modes[rowoff + xl] = (uint8_t)mbyte;
 }
 
 // ---------------------------------------------------------------------------
@@ -1935,7 +1948,7 @@ __global__ __launch_bounds__(256) void sum_modes_kernel(const uint8_t *__restric
 {
     unsigned long long s = 0;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
-        s += modes[i];
+        s += modes[i] & kModeCount;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1)
         s += __shfl_down(s, off, 64);
