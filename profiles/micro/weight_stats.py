@@ -27,3 +27,7 @@ for T in (512, 520, 1024):
     vals, cnt = np.unique(w0[nm == 1], return_counts=True)
     o = np.argsort(-cnt)[:6]
     print("    commonest single-mode weights:", [(float(vals[i]), int(cnt[i])) for i in o])
+    v0 = st["var"][0].reshape(S * h, w // 64, 64)
+    at_min = (nm == 1) & (v0 == np.float32(4.0))
+    print("    px single-mode with variance at var_min: %.4f | segments where all are: %.4f"
+          % (at_min.mean(), at_min.all(axis=2).mean()))
