@@ -103,13 +103,15 @@ def cpu_baseline(frames_host, h, w, budget_s):
 def load_traffic(path, key):
     """HBM bytes per launch from the committed PMC passes (profiles/), if the
     recorded configuration matches this run; else None."""
-    try:
-        with open(path) as f:
-            rec = json.load(f)
-        if rec.get("config") == key:
-            return rec.get("hbm_bytes_per_launch")
-    except Exception:
-        pass
+    # the named file, then the per-frame record kept next to it
+    for cand in (path, os.path.join(os.path.dirname(path), "r01_traffic_T1.json")):
+        try:
+            with open(cand) as f:
+                rec = json.load(f)
+            if rec.get("config") == key:
+                return rec.get("hbm_bytes_per_launch")
+        except Exception:
+            pass
     return None
 
 
