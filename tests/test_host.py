@@ -85,6 +85,41 @@ def test_find_contours_random_matches_scipy_components():
             assert (x, y, w, h) == (comp[1].min(), comp[0].min(), np.ptp(comp[1]) + 1, np.ptp(comp[0]) + 1)
 
 
+@pytest.mark.parametrize("shape", [(300, 1003), (97, 131), (64, 33), (1, 70), (70, 1), (9, 8), (33, 64)])
+def test_find_contours_sparse_masks(shape):
+    """Mostly-empty masks of widths around the 8- and 32-byte strides the scan skips
+    zeros with: small blobs at random places (edges and stride boundaries included),
+    alternating with other geometries in between (the per-thread label buffer must
+    come back clean).  One external contour per 8-connected component, same bounding
+    box, and the same answer when asked again."""
+    from scipy import ndimage
+    h, w = shape
+    rng = np.random.default_rng(h * 1000 + w)
+    for rep in range(6):
+        m = np.zeros((h, w), np.uint8)
+        for _ in range(int(rng.integers(1, 9))):
+            y, x = int(rng.integers(0, h)), int(rng.integers(0, w))
+            bh, bw = int(rng.integers(1, 8)), int(rng.integers(1, 12))
+            m[y:y + bh, x:x + bw] = rng.choice([1, 127, 255])
+        m[rng.random((h, w)) > 0.995] = 255           # isolated pixels
+        lab, n = ndimage.label(m, structure=np.ones((3, 3)))
+        cs = find_contours(m)
+        find_contours(np.full((7, 5 + rep), 255, np.uint8))        # another geometry in between
+        assert len(cs) == n        # solid blobs and dots: every component is external
+        again = find_contours(m)
+        assert len(again) == len(cs) and all(np.array_equal(a, b) for a, b in zip(again, cs))
+        seen = set()
+        for c in cs:
+            ids = {lab[y, x] for x, y in c[:, 0]}
+            assert len(ids) == 1
+            cid = ids.pop()
+            seen.add(cid)
+            x, y, bw, bh = hostcv.boundingRect(c)
+            comp = np.nonzero(lab == cid)
+            assert (x, y, bw, bh) == (comp[1].min(), comp[0].min(), np.ptp(comp[1]) + 1, np.ptp(comp[0]) + 1)
+        assert seen == set(range(1, n + 1))
+
+
 def test_polygon_tests_and_moments():
     sq = np.array([[0, 0], [0, 10], [10, 10], [10, 0]])
     assert hostcv.pointPolygonTest(sq, (5, 5)) == 1
