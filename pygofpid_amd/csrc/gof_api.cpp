@@ -950,6 +950,9 @@ void gof_pipeline_destroy(gof_pipeline *p)
     p->blurred.release();
     p->m0.release();
     p->m1.release();
+    p->rowflags.release();
+    p->fd_prev[0].release();
+    p->fd_prev[1].release();
     if (p->d_sum)
         (void)hipFree(p->d_sum);
     for (hipEvent_t e : p->events)
