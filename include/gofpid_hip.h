@@ -18,6 +18,21 @@
  *   - *_host entry points borrow host buffers for the duration of the call and
  *     are synchronous.  *_dev entry points take device pointers, enqueue on the
  *     stream and return without synchronising.
+ *   - streams: `stream == NULL` means the CONTEXT's own stream (gof_stream(ctx), created
+ *     non-blocking), NOT HIP's legacy default stream 0: a caller whose producer
+ *     kernels run on stream 0 must either pass gof_stream(ctx) to them or
+ *     synchronise before the call.  All *_dev calls on ONE object (gof_mog2, gof_fd,
+ *     gof_pipeline) must be issued on ONE stream, or the caller orders the streams
+ *     itself: the objects keep device state and scratch that successive calls
+ *     read and write without further synchronisation.  Objects are complete when
+ *     their create call returns (the zero-fill of a model is waited for), and the
+ *     host-visible model accesses (export, import, state_copy, mean_modes) first wait
+ *     for the stream the last apply was enqueued on.
+ *   - device buffers need no particular alignment and no slack: no kernel reads or
+ *     writes a byte outside the buffers' stated sizes.  The fast paths need frames
+ *     whose base, row pitch (w*c) and image size are multiples of 4 bytes (true for
+ *     every common geometry); anything else runs a slower general path with the
+ *     same results.
  *   - a context is bound to one device and is NOT thread-safe; distinct
  *     contexts are independent (the reference runs one GOFPID per video,
  *     examples/dataset_ilids.py:126-140).
@@ -124,7 +139,9 @@ int gof_gaussian_blur_dev(gof_ctx *ctx, const void *d_src, void *d_dst, int n_im
 /* cv.blur(src, (kw, kh)) on uint8: normalised box filter, BORDER_REFLECT_101,
  * out = round-half-even(sum / (kw*kh)).  The reference's tests call it as
  * blur['fun'](X, ksize, borderType) (tests/test_pipeline.py:68-75): cv2 binds that
- * third positional argument to `dst`, so the requested border is ignored. */
+ * third positional argument to `dst`, so the requested border is ignored.
+ * Only odd kw / kh are accepted (GOF_EINVAL otherwise): cv2 also takes even sizes
+ * (anchor at k/2), which the reference never uses (3x3, tests/test_pipeline.py:68-75). */
 int gof_box_blur_host(gof_ctx *ctx, const uint8_t *src, uint8_t *dst, int h, int w, int c, int kw,
                       int kh);
 int gof_box_blur_dev(gof_ctx *ctx, const void *d_src, void *d_dst, int n_images, int h, int w,

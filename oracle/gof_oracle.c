@@ -18,6 +18,35 @@
  * vectors and (iii) independent scipy.ndimage cross-checks in
  * tests/test_oracle.py.
  *
+ * OPENCV VERSION EACH CHOICE ASSUMES (all from recollection of the public sources;
+ * nothing below could be run against cv2 here -- this is the list a maintainer with
+ * cv2 checks FIRST, most output-changing item first):
+ *   1. GaussianBlur, 8-bit, taps for (3,3), sigma 4:  [84, 88, 84]  (sum 256)
+ *        = the fixed-point path WITH error-diffused tap rounding
+ *        (getGaussianKernelFixedPoint_ED), as in 3.4.9+ / 4.2+.
+ *        3.4.1 .. 3.4.8 (fixed point, every tap rounded on its own) give
+ *        [84, 87, 84] (sum 255): constant images come out one grey level darker
+ *        where 255*c/256 rounds down.  3.4.0 ran the float filter engine
+ *        (cvRound of a float convolution): differs in the last bit on ~half the
+ *        pixels.  Probe: cv.GaussianBlur(np.full((8,8),200,np.uint8),(3,3),4)
+ *        -> 200 everywhere iff error-diffused.  tests/test_oracle.py pins the choice.
+ *   2. cvtColor BGR/RGB -> GRAY: shift 14, (B,G,R) = (1868, 9617, 4899), the 3.4 line
+ *        (RGB2Gray<uchar> table).  4.x SIMD path: shift 15, (3735, 19235, 9798); the
+ *        two differ by one grey level on a few percent of inputs.  Probe: the pixel
+ *        (B,G,R) = (1,2,253) and a sweep over one channel.
+ *   3. cv.blur (box): rint(sum * (1.0/area)) in double (ColumnSum<int,uchar>).  Later
+ *        3.4.x / 4.x use an integer ColumnSum<ushort,uchar> = (sum + area/2) / area:
+ *        identical for every ODD area (no ties exist), which is all this library
+ *        accepts; even sizes (refused here) are where the two differ.
+ *   4. MOG2 weight renormalisation guarded by |totalWeight| > FLT_EPSILON (4.x and late
+ *        3.4.x).  Older 3.4 divides unguarded: only differs when every mode of a pixel
+ *        was pruned in one frame (totalWeight == 0 -> inf/NaN there), which the default
+ *        rates cannot produce (prune = -0.05 alpha, weights sum to ~1).
+ *   5. MOG2 shadow test runs on the model AFTER the frame's update, mask 127; learning
+ *        rate 1/min(2 n, history) in double: unchanged across 3.4 / 4.x.
+ *   6. erode / dilate with BORDER_CONSTANT, borderValue = morphologyDefaultBorderValue
+ *        (never wins a min / max): unchanged across versions.
+ *
  * Reference call sites restated here:
  *   pipeline.py:462-467   blur['fun'](X, ksize, borderType)
  *                         default cv.GaussianBlur(X,(3,3),4): the 3rd positional

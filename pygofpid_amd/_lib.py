@@ -187,6 +187,22 @@ def as_u8(x, name="X"):
     return np.ascontiguousarray(x)
 
 
+def mog2_state_arrays(state, K, c, n):
+    """The four arrays of an exported MOG2 model as C-contiguous arrays of exactly the
+    shapes gof_mog2_import reads -- weight (K, n), var (K, n), mean (K, c, n) float32,
+    modes (n,) uint8 -- or ValueError (a checkpoint written with another nmixtures or
+    geometry must not reach the C side, which trusts the sizes)."""
+    out = []
+    for key, shape, dt in (("weight", (K, n), np.float32), ("var", (K, n), np.float32),
+                           ("mean", (K, c, n), np.float32), ("modes", (n,), np.uint8)):
+        a = np.asarray(state[key])
+        if a.shape != shape:
+            raise ValueError("MOG2 state %r has shape %r, this model needs %r (nmixtures=%d)"
+                             % (key, a.shape, shape, K))
+        out.append(np.ascontiguousarray(a, dt))
+    return out
+
+
 def hwc(x):
     """(H,W) | (H,W,1) | (H,W,C) -> (array, h, w, c)"""
     if x.ndim == 2:

@@ -84,6 +84,9 @@ struct gof_mog2 {
     size_t np = 0;           // plane pitch in floats
     size_t state_bytes = 0;
     void *state = nullptr;   // [K*(2+c)] float planes of pitch np, then modes[np]
+    // the stream the last apply was enqueued on: export / import / state_copy /
+    // mean_modes run on ctx->stream and wait for it first when it is another one
+    hipStream_t last = nullptr;
     DevBuf in, out;
     gofk::Mog2State view() const
     {
@@ -202,6 +205,15 @@ int check_geom(int n, int h, int w, int c)
 }
 
 hipStream_t pick(gof_ctx *ctx, void *stream) { return stream ? (hipStream_t)stream : ctx->stream; }
+
+// Host-visible accesses to the model (export, import, state_copy, mean_modes) run on
+// the context's stream; applies may have been enqueued on a caller's stream.
+hipError_t drain_applies(gof_mog2 *m)
+{
+    if (m->last && m->last != m->ctx->stream)
+        return hipStreamSynchronize(m->last);
+    return hipSuccess;
+}
 
 // Constants of the next T (<= kMaxT) frames; advances the frame counter by T.
 // cv2 BackgroundSubtractorMOG2Impl::apply with learningRate = -1 [OPENCV-RECALL]:
@@ -568,11 +580,16 @@ int gof_mog2_create(gof_ctx *ctx, int streams, int h, int w, int c, const gof_mo
         return fail(GOF_ENOMEM, "hipMalloc(%zu B of MOG2 state): %s", m->state_bytes,
                     hipGetErrorString(e));
     }
+    // Zero-fill and WAIT: the *_dev entry points may be given any caller stream, which is
+    // not ordered against ctx->stream (created non-blocking); the model must be complete
+    // before create returns.  Not on the hot path.
     e = hipMemsetAsync(m->state, 0, m->state_bytes, ctx->stream);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
         (void)hipFree(m->state);
         delete m;
-        return fail(GOF_EHIP, "hipMemsetAsync: %s", hipGetErrorString(e));
+        return fail(GOF_EHIP, "zero-filling the MOG2 state: %s", hipGetErrorString(e));
     }
     *out = m;
     return GOF_OK;
@@ -608,9 +625,10 @@ int gof_mog2_apply_dev(gof_mog2 *m, const void *d_frames, void *d_masks, void *s
     GOF_HIP(hipSetDevice(m->ctx->device));
     gofk::Mog2Consts k = next_consts(m, 1);
     gofk::Taps none{};
+    m->last = pick(m->ctx, stream);
     hipError_t e = gofk::mog2_apply((const uint8_t *)d_frames, (uint8_t *)d_masks, m->view(),
                                     m->streams, m->h, m->w, m->c, 1, k, false, none,
-                                    pick(m->ctx, stream));
+                                    m->last, nullptr, nullptr, (size_t)m->streams * m->h * m->w * m->c);
     if (e != hipSuccess) {
         --m->nframes;
         return fail(GOF_EHIP, "mog2 launch: %s", hipGetErrorString(e));
@@ -641,6 +659,7 @@ int gof_mog2_export(gof_mog2 *m, float *weight, float *var, float *mean, uint8_t
     if (!m || !weight || !var || !mean || !modes)
         return fail(GOF_EINVAL, "NULL argument");
     GOF_HIP(hipSetDevice(m->ctx->device));
+    GOF_HIP(drain_applies(m));
     hipStream_t s = m->ctx->stream;
     const size_t n = (size_t)m->streams * m->h * m->w, np = m->np;
     const int K = m->p.nmixtures, C = m->c, F = 2 + C;
@@ -668,6 +687,7 @@ int gof_mog2_import(gof_mog2 *m, const float *weight, const float *var, const fl
     if (!m || !weight || !var || !mean || !modes || nframes < 0)
         return fail(GOF_EINVAL, "bad argument");
     GOF_HIP(hipSetDevice(m->ctx->device));
+    GOF_HIP(drain_applies(m));
     hipStream_t s = m->ctx->stream;
     const size_t n = (size_t)m->streams * m->h * m->w, np = m->np;
     const int K = m->p.nmixtures, C = m->c, F = 2 + C;
@@ -705,6 +725,7 @@ int gof_mog2_state_copy(gof_mog2 *m, void *d_buf, int to_model)
     if (!m || !d_buf)
         return fail(GOF_EINVAL, "NULL argument");
     GOF_HIP(hipSetDevice(m->ctx->device));
+    GOF_HIP(drain_applies(m));
     hipStream_t s = m->ctx->stream;
     if (to_model)
         GOF_HIP(hipMemcpyAsync(m->state, d_buf, m->state_bytes, hipMemcpyDeviceToDevice, s));
@@ -1031,9 +1052,11 @@ int gof_pipeline_apply_dev_many(gof_pipeline *p, const void *d_frames, void *d_m
             gofk::Mog2Consts k = next_consts(p->mog2, tn);
             uint8_t *rfc = rf ? rf + (size_t)(t0 / gofk::kMaxT) * rf_chunk : nullptr;
             bool written = false;
+            p->mog2->last = s;
             hipError_t e = gofk::mog2_apply(x + (size_t)t0 * npx * d.c, det_out + (size_t)t0 * npx,
                                             p->mog2->view(), d.streams, d.h, d.w, d.c, tn, k,
-                                            p->fuse_blur3, p->taps, s, rfc, &written);
+                                            p->fuse_blur3, p->taps, s, rfc, &written,
+                                            (size_t)(T - t0) * npx * d.c);
             if (e != hipSuccess) {
                 p->mog2->nframes -= tn;
                 return fail(GOF_EHIP, "mog2 launch: %s", hipGetErrorString(e));
@@ -1184,6 +1207,7 @@ int gof_pipeline_mean_modes(gof_pipeline *p, double *mean_modes)
     if (!p->mog2)
         return GOF_OK;
     GOF_HIP(hipSetDevice(p->ctx->device));
+    GOF_HIP(drain_applies(p->mog2));
     hipStream_t s = p->ctx->stream;
     const size_t n = (size_t)p->d.streams * p->d.h * p->d.w;
     unsigned long long sum = 0;

@@ -93,10 +93,12 @@ hipError_t blur_sep_q8(const uint8_t *src, uint8_t *dst, int n_img, int h, int w
 // kernel runs it writes, per image row and 64-px tile column, a byte whose bit t
 // says "the mask of frame t is not all zero there" (conservative) and sets
 // *rowflags_written; morph_rect_chain uses that to skip reading all-zero regions.
+// frame_bytes: bytes readable from `frame` (>= T * n_img*h*w*c); no kernel reads a
+// byte outside [frame, frame + T * n_img*h*w*c), whatever the alignment of `frame`.
 inline int rowflag_pitch(int w) { return (w + 63) / 64; }
 hipError_t mog2_apply(const uint8_t *frame, uint8_t *mask, const Mog2State &st, int n_img, int h,
                       int w, int c, int T, const Mog2Consts &k, bool fused_blur3, const Taps &t,
-                      hipStream_t s, uint8_t *rowflags = nullptr, bool *rowflags_written = nullptr);
+                      hipStream_t s, uint8_t *rowflags, bool *rowflags_written, size_t frame_bytes);
 
 hipError_t fd_apply(const uint8_t *cur, const uint8_t *prev, bool has_prev, int ithr,
                     uint8_t *mask, int n_img, int h, int w, int c, hipStream_t s);

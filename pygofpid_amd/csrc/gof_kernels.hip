@@ -445,7 +445,7 @@ __global__ __launch_bounds__(256, (!MULTI && ALN && C <= 3) ? 8 : 1) void mog2_k
                                                    int W, int T_arg, size_t frame_stride,
                                                    size_t mask_stride, Mog2Consts k, uint32_t kx012,
                                                    uint32_t ky012, uint8_t *__restrict__ rowflags,
-                                                   int flag_pitch)
+                                                   int flag_pitch, const uint8_t *frame_end)
 {
     constexpr int F = 2 + C;  // floats per mode
     const int T = MULTI ? T_arg : 1;
@@ -488,7 +488,23 @@ __global__ __launch_bounds__(256, (!MULTI && ALN && C <= 3) ? 8 : 1) void mog2_k
 #pragma unroll
                     for (int q = 0; q < NDW; q++) {
                         const int d = lane + 64 * q;
-                        raw[ti][rr][q] = d < ndw ? ((const uint32_t *)(a - mis))[d] : 0u;
+                        uint32_t v = 0u;
+                        if (d < ndw) {
+                            const uint8_t *p4 = a - mis + 4 * d;
+                            // Aligned frames end on a dword boundary.  Otherwise the dword
+                            // holding a row's first / last byte may straddle the caller's
+                            // buffer [frame, frame_end): those (at most two per launch) are
+                            // assembled from the bytes inside it -- nothing outside is read.
+                            if (ALN || (p4 >= frame && p4 + 4 <= frame_end)) {
+                                v = *(const uint32_t *)p4;
+                            } else {
+#pragma unroll
+                                for (int b = 0; b < 4; b++)
+                                    if (p4 + b >= frame && p4 + b < frame_end)
+                                        v |= (uint32_t)p4[b] << (8 * b);
+                            }
+                        }
+                        raw[ti][rr][q] = v;
                     }
                 }
             }
@@ -2006,7 +2022,7 @@ hipError_t blur_sep_q8(const uint8_t *src, uint8_t *dst, int n_img, int h, int w
 
 hipError_t mog2_apply(const uint8_t *frame, uint8_t *mask, const Mog2State &st, int n_img, int h,
                       int w, int c, int T, const Mog2Consts &k, bool fused_blur3, const Taps &t,
-                      hipStream_t s, uint8_t *rowflags, bool *rowflags_written)
+                      hipStream_t s, uint8_t *rowflags, bool *rowflags_written, size_t frame_bytes)
 {
     if (rowflags_written)
         *rowflags_written = rowflags != nullptr;   // every MOG2 kernel writes them
@@ -2022,6 +2038,9 @@ hipError_t mog2_apply(const uint8_t *frame, uint8_t *mask, const Mog2State &st, 
     }
     // frames [T][n_img][h][w][c], masks [T][n_img][h][w]
     const size_t fstride = (size_t)n_img * h * w * c, mstride = (size_t)n_img * h * w;
+    if (frame_bytes < (size_t)T * fstride)
+        return hipErrorInvalidValue;
+    const uint8_t *frame_end = frame + (size_t)T * fstride;   // the kernels read nothing past it
     dim3 g = grid3(w, h, n_img, TW, TH);
     // invariant window addressing needs every staged row of every frame to start at
     // the same offset mod 4
@@ -2056,7 +2075,7 @@ hipError_t mog2_apply(const uint8_t *frame, uint8_t *mask, const Mog2State &st, 
 #define GOF_LAUNCH_MOG2_(CC, BB, MM, AA)                                                         \
     hipLaunchKernelGGL((mog2_kernel<CC, BB, MM, AA>), g, dim3(256), 0, s, frame, mask,           \
                        st.planes, st.modes, st.np, h, w, T, fstride, mstride, k, kx, ky, rowflags,      \
-                       rowflag_pitch(w))
+                       rowflag_pitch(w), frame_end)
 #define GOF_LAUNCH_MOG2(CC, BB)                                                                  \
     do {                                                                                         \
         if (T == 1 && aln)                                                                       \

@@ -205,10 +205,7 @@ class BackgroundSubtractorMOG2:
         h, w, c = shape
         self._ensure(h, w, c)
         f32 = C.POINTER(C.c_float)
-        wt = np.ascontiguousarray(state["weight"], np.float32)
-        var = np.ascontiguousarray(state["var"], np.float32)
-        mean = np.ascontiguousarray(state["mean"], np.float32)
-        modes = np.ascontiguousarray(state["modes"], np.uint8)
+        wt, var, mean, modes = _lib.mog2_state_arrays(state, self._params.nmixtures, c, h * w)
         _lib.check(_lib.load().gof_mog2_import(self._h, wt.ctypes.data_as(f32),
                                                var.ctypes.data_as(f32), mean.ctypes.data_as(f32),
                                                _lib.p8(modes), int(state["nframes"])))

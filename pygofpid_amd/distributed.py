@@ -92,10 +92,25 @@ def broadcast_model(state, nframes, src=0):
 
 
 def warm_start(pipe, src=0):
-    """Broadcast the model of `pipe` (a MOG2 ForegroundPipeline) from rank src."""
+    """Broadcast the model of `pipe` (a MOG2 ForegroundPipeline) from rank src.
+
+    Every rank must hold a pipeline of the same geometry and nmixtures: the sizes
+    are compared over the group first (a mismatch would hang or corrupt the
+    broadcast) and ValueError is raised on every rank if they differ.  With one
+    process this is a copy of the model through the staging buffer."""
     import torch
+    import torch.distributed as dist
     _, nbytes = pipe.mog2_device_state()
-    buf = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    dev = torch.device("cuda", pipe.device)
+    if dist.is_available() and dist.is_initialized():
+        mine = torch.tensor([nbytes, pipe.streams, pipe.h, pipe.w, pipe.c, pipe.nmixtures],
+                            dtype=torch.int64, device=dev)
+        every = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(every, mine)
+        if any(not torch.equal(e, every[src]) for e in every):
+            raise ValueError("warm_start: ranks hold different models: %r"
+                             % [e.tolist() for e in every])
+    buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     pipe.state_to_buffer(buf.data_ptr())
     n = broadcast_model(buf, pipe.nframes(), src=src)
     pipe.state_from_buffer(buf.data_ptr(), n)

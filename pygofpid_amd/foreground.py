@@ -57,6 +57,7 @@ class ForegroundPipeline:
             lib.gof_mog2_default_params(C.byref(d.mog2))
         else:
             d.mog2 = mog2_params
+        self.nmixtures = int(d.mog2.nmixtures)
         d.fd_threshold = float(fd_threshold)
         morph = list(morph or [])
         if len(morph) > _lib.MAX_MORPH:
@@ -116,6 +117,11 @@ class ForegroundPipeline:
     def stream(self):
         return self._ctx.stream
 
+    @property
+    def device(self):
+        """HIP device index of the pipeline's context."""
+        return int(self._ctx.device)
+
     def synchronize(self):
         self._ctx.synchronize()
 
@@ -152,7 +158,7 @@ class ForegroundPipeline:
         m = _lib.load().gof_pipeline_mog2(self._h)
         if not m:
             raise RuntimeError("not a MOG2 pipeline")
-        n, K, c = self.streams * self.h * self.w, 5, self.c
+        n, K, c = self.streams * self.h * self.w, self.nmixtures, self.c
         wt, var = np.empty((K, n), np.float32), np.empty((K, n), np.float32)
         mean, modes = np.empty((K, c, n), np.float32), np.empty(n, np.uint8)
         f32 = C.POINTER(C.c_float)
@@ -165,7 +171,8 @@ class ForegroundPipeline:
         """Checkpoint the background model (the reference never serialises it, SURVEY.md
         section 5): an .npz of the SoA planes plus the frame counter and geometry."""
         st = self.mog2_state()
-        np.savez_compressed(path, geometry=np.array([self.streams, self.h, self.w, self.c]), **st)
+        np.savez_compressed(path, geometry=np.array([self.streams, self.h, self.w, self.c]),
+                            nmixtures=np.array(self.nmixtures), **st)
 
     def load_state(self, path):
         """Restore a checkpoint written by save_state() into this pipeline."""
@@ -177,10 +184,11 @@ class ForegroundPipeline:
             if not m:
                 raise RuntimeError("not a MOG2 pipeline")
             f32 = C.POINTER(C.c_float)
-            wt = np.ascontiguousarray(z["weight"], np.float32)
-            var = np.ascontiguousarray(z["var"], np.float32)
-            mean = np.ascontiguousarray(z["mean"], np.float32)
-            modes = np.ascontiguousarray(z["modes"], np.uint8)
+            if "nmixtures" in z.files and int(z["nmixtures"]) != self.nmixtures:
+                raise ValueError("checkpoint has nmixtures=%d, this pipeline %d"
+                                 % (int(z["nmixtures"]), self.nmixtures))
+            wt, var, mean, modes = _lib.mog2_state_arrays(
+                z, self.nmixtures, self.c, self.streams * self.h * self.w)
             _lib.check(_lib.load().gof_mog2_import(m, wt.ctypes.data_as(f32), var.ctypes.data_as(f32),
                                                    mean.ctypes.data_as(f32), _lib.p8(modes),
                                                    int(z["nframes"])))

@@ -1,0 +1,178 @@
+"""GPU tests of the C-ABI boundary conditions (run on a real MI355X through gpurun):
+caller streams, caller-owned device buffers of any alignment, and the warm-start /
+checkpoint hand-over of the MOG2 model.  Checker: the CPU oracle, bit-exact."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from pygofpid_amd.synth import Clip
+
+pytestmark = pytest.mark.gpu
+
+
+def test_warm_start_device_path(oracle):
+    """pipeline A trains, its model travels through a device buffer
+    (state_to_buffer -> state_from_buffer + nframes, the RCCL broadcast's payload) into a
+    fresh pipeline B; A and B then give identical masks and identical exported state for
+    the next 16 frames, through an 8-frame launch and single-frame launches, and both
+    match the oracle that saw the whole clip."""
+    import torch
+    from pygofpid_amd.foreground import ForegroundPipeline
+    S, h, w, c = 2, 72, 128, 3
+    clips = [Clip(h, w, c, seed=70 + s, n_objects=3) for s in range(S)]
+    refs = [oracle.Pipeline(h, w, c) for _ in range(S)]
+    a = ForegroundPipeline((h, w, c), streams=S)
+    for t0 in range(0, 24, 8):
+        fr = np.stack([np.stack([cl.frame(t0 + i) for cl in clips]) for i in range(8)])
+        got = a.apply_many(fr)
+        for i in range(8):
+            for s in range(S):
+                assert np.array_equal(got[i, s], refs[s].apply(fr[i, s]))
+    _, nbytes = a.mog2_device_state()
+    buf = torch.empty(nbytes, dtype=torch.uint8, device=torch.device("cuda", a.device))
+    a.state_to_buffer(buf.data_ptr())
+    b = ForegroundPipeline((h, w, c), streams=S)
+    assert b.nframes() == 0
+    b.state_from_buffer(buf.data_ptr(), a.nframes())
+    assert b.nframes() == a.nframes() == 24
+    fr = np.stack([np.stack([cl.frame(24 + i) for cl in clips]) for i in range(8)])
+    ma, mb = a.apply_many(fr), b.apply_many(fr)
+    assert np.array_equal(ma, mb)
+    for i in range(8):
+        for s in range(S):
+            assert np.array_equal(ma[i, s], refs[s].apply(fr[i, s]))
+    for t in range(32, 40):
+        f = np.stack([cl.frame(t) for cl in clips])
+        ma, mb = a.apply(f), b.apply(f)
+        assert np.array_equal(ma, mb)
+        for s in range(S):
+            assert np.array_equal(ma[s], refs[s].apply(f[s]))
+    sa, sb = a.mog2_state(), b.mog2_state()
+    assert sa["nframes"] == sb["nframes"] == 40
+    assert np.array_equal(sa["modes"], sb["modes"])
+    live = np.arange(a.nmixtures)[:, None] < sa["modes"][None, :]
+    for key in ("weight", "var"):
+        assert np.array_equal(sa[key][live], sb[key][live])
+    assert np.array_equal(sa["mean"][np.broadcast_to(live[:, None, :], sa["mean"].shape)],
+                          sb["mean"][np.broadcast_to(live[:, None, :], sb["mean"].shape)])
+
+
+def test_warm_start_single_process():
+    """distributed.warm_start() with no process group: the model makes the round trip
+    through the staging buffer on the pipeline's own device and nothing changes."""
+    from pygofpid_amd import distributed as gd
+    from pygofpid_amd.foreground import ForegroundPipeline
+    h, w, c = 48, 64, 3
+    clip = Clip(h, w, c, seed=5)
+    a, b = ForegroundPipeline((h, w, c)), ForegroundPipeline((h, w, c))
+    for t in range(6):
+        f = clip.frame(t)
+        assert np.array_equal(a.apply(f), b.apply(f))
+    assert gd.warm_start(a) == 6
+    for t in range(6, 12):
+        f = clip.frame(t)
+        assert np.array_equal(a.apply(f), b.apply(f))
+
+
+def test_apply_on_caller_stream_right_after_create(oracle):
+    """the model's zero-fill runs on the context's stream; an apply enqueued on
+    ANOTHER stream immediately after create must see the finished model, and the export
+    that follows must see the finished apply."""
+    import torch
+    from pygofpid_amd.foreground import ForegroundPipeline
+    S, h, w, c = 8, 540, 960, 3     # 0.4 GB of model: the fill takes a while
+    rng = np.random.default_rng(3)
+    frames = rng.integers(0, 255, (2, S, h, w, c), dtype=np.uint8)
+    dev = torch.device("cuda", 0)
+    d_frames = torch.from_numpy(frames).to(dev)
+    d_masks = torch.empty((S, h, w), dtype=torch.uint8, device=dev)
+    side = torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+    pipe = ForegroundPipeline((h, w, c), streams=S, device=0)
+    refs = [oracle.Pipeline(h, w, c) for _ in range(S)]
+    for t in range(2):
+        pipe.apply_device(d_frames[t].data_ptr(), d_masks.data_ptr(), stream=side.cuda_stream)
+        if t == 1:
+            st = pipe.mog2_state()     # waits for `side` itself
+        side.synchronize()
+        got = d_masks.cpu().numpy()
+        for s in range(S):
+            assert np.array_equal(got[s], refs[s].apply(frames[t, s])), (t, s)
+    assert st["nframes"] == 2
+    for s in range(S):
+        want = refs[s].export()
+        n = h * w
+        assert np.array_equal(st["modes"][s * n:(s + 1) * n], want["modes"])
+
+
+@pytest.mark.parametrize("offset", [0, 1, 2, 3])
+@pytest.mark.parametrize("shape", [(37, 53, 3), (40, 64, 3), (31, 30, 1), (24, 32, 4)])
+def test_device_buffers_any_alignment(oracle, offset, shape):
+    """*_dev callers owe no alignment and no slack.  The frames sit at
+    byte `offset` of a torch allocation and END on its last byte; masks likewise.  Odd
+    offsets and ragged rows take the general staging path, whose first / last dword is
+    assembled from in-buffer bytes only.  One- and multi-frame calls."""
+    import torch
+    from pygofpid_amd.foreground import ForegroundPipeline
+    h, w, c = shape
+    T = 3
+    clip = Clip(h, w, c, seed=11 + offset, n_objects=2)
+    frames = np.stack([clip.frame(t) for t in range(2 * T)]).reshape(2 * T, h, w, c)
+    dev = torch.device("cuda", 0)
+    nb, nm = T * h * w * c, T * h * w
+    fbuf = torch.empty(offset + nb, dtype=torch.uint8, device=dev)
+    mbuf = torch.full((offset + nm,), 7, dtype=torch.uint8, device=dev)
+    fview, mview = fbuf[offset:], mbuf[offset:]
+    assert fview.data_ptr() % 4 == (fbuf.data_ptr() + offset) % 4
+    pipe = ForegroundPipeline((h, w, c), device=0)
+    ref = oracle.Pipeline(h, w, c)
+    # T frames in one call, then T single-frame calls
+    fview.copy_(torch.from_numpy(frames[:T].reshape(-1)).to(dev))
+    pipe.apply_device(fview.data_ptr(), mview.data_ptr(), n_frames=T)
+    pipe.synchronize()
+    got = mview.cpu().numpy().reshape(T, h, w)
+    for t in range(T):
+        assert np.array_equal(got[t], ref.apply(frames[t].reshape(h, w, c) if c > 1 else frames[t, :, :, 0])), t
+    if offset:
+        assert (mbuf[:offset].cpu().numpy() == 7).all()      # nothing written before the view
+    fview.copy_(torch.from_numpy(frames[T:].reshape(-1)).to(dev))
+    for t in range(T):
+        pipe.apply_device(fview[t * h * w * c:].data_ptr(), mview[t * h * w:].data_ptr())
+    pipe.synchronize()
+    got = mview.cpu().numpy().reshape(T, h, w)
+    for t in range(T):
+        assert np.array_equal(got[t], ref.apply(frames[T + t].reshape(h, w, c) if c > 1 else frames[T + t, :, :, 0])), t
+
+
+def test_state_shape_validation(tmp_path):
+    """a checkpoint written with another nmixtures (or mangled arrays) is refused
+    in Python, before the C side would read K * n floats from too small an array."""
+    from pygofpid_amd import _lib, cv
+    from pygofpid_amd.foreground import ForegroundPipeline
+    h, w, c = 24, 32, 3
+    p3 = _lib.Mog2Params()
+    _lib.load().gof_mog2_default_params(C.byref(p3))
+    p3.nmixtures = 3
+    a = ForegroundPipeline((h, w, c), mog2_params=p3)
+    f = Clip(h, w, c, seed=1).frame(0)
+    a.apply(f)
+    st = a.mog2_state()
+    assert st["weight"].shape == (3, h * w) and st["mean"].shape == (3, c, h * w)
+    path = str(tmp_path / "k3.npz")
+    a.save_state(path)
+    with pytest.raises(ValueError):
+        ForegroundPipeline((h, w, c)).load_state(path)           # K = 5 model, K = 3 file
+    b = ForegroundPipeline((h, w, c), mog2_params=p3)
+    b.load_state(path)
+    f1 = Clip(h, w, c, seed=1).frame(1)
+    assert np.array_equal(a.apply(f1), b.apply(f1))
+    m = cv.createBackgroundSubtractorMOG2()
+    with pytest.raises(ValueError):
+        m.import_state(st, (h, w, c))                            # K = 3 arrays into K = 5
+    bad = dict(a.mog2_state())
+    bad["modes"] = bad["modes"][:-1]
+    with pytest.raises(ValueError):
+        b_ = ForegroundPipeline((h, w, c), mog2_params=p3)
+        np.savez(str(tmp_path / "bad.npz"), geometry=np.array([1, h, w, c]), nmixtures=np.array(3), **bad)
+        b_.load_state(str(tmp_path / "bad.npz"))
