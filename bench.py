@@ -6,24 +6,48 @@
 Workload (BASELINE.json configs[1]): 1920x1080 BGR frames, GaussianBlur 3x3
 (sigma 4, as the reference calls it) -> MOG2 -> erode 5x5 -> dilate 5x5, i.e.
 steps 1-3 of GOFPID.detect (pygofpid/pipeline.py:461-476).  One "step" is one
-pass of the path over one batch: one new frame for each of `--streams`
-independent video streams (8 by default, so that the background models,
-~0.4-1.7 GB in use, do not fit the 256 MiB Infinity Cache).  Frames are
+pass of the path over one batch: `--frames-per-step` consecutive frames of each
+of `--streams` independent video streams (8 x 8 by default; the background
+models, ~0.5-1.7 GB in use, do not fit the 256 MiB Infinity Cache).  Frames are
 synthetic and already resident in HBM when the timed region starts.
+
+Protocol:
+  1. pre-roll: real steps for >= --preroll-seconds (0.5 s) AND >= 256 frames per
+     stream, whatever --warmup says: the learning rate 1/min(2t, history) has
+     reached 1/history and the clocks have settled under load;
+  2. W further untimed warm-up steps;
+  3. R (--rounds, 10) rounds of EXACTLY K steps, each bracketed by a barrier +
+     device synchronisation on both sides and reduced with MAX over ranks;
+     the MEDIAN round is reported (`ms_per_step`, `value`), min / max alongside;
+  4. two more rounds of K steps with HIP events around every kernel, on the
+     launch stream, for the roofline block (kept out of the timed rounds: an
+     event pair costs the stream a few microseconds).
 
 N > 1: one process per GPU (torch.distributed / RCCL only for the barrier and
 the MAX over ranks); every rank steps its own streams -- the path shards by
 stream with no data-path collective ("weak" scaling).
 
-Prints ONE JSON line on rank 0, including
-  roofline      -- dominant kernel (fused blur + MOG2): algorithmic bytes per
-                   launch / HIP-event time on the launch stream vs 8 TB/s
+Prints ONE JSON line on rank 0, with
+  roofline      -- the dominant kernel (fused blur + MOG2) against the roofline that
+                   bounds it.  8 frames per launch: vector-instruction issue (the
+                   model crosses HBM once per 8 frames, so memory is out of the way):
+                   frac = SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x 2.4 GHz x t), with
+                   SQ_INSTS_VALU from the committed PMC pass of this configuration;
+                   `hbm` = the launch's own algorithmic bytes / t against 8 TB/s.
+                   1 frame per launch: HBM (algorithmic bytes / t / 8 TB/s).
+                   Every frac is <= 1 by construction of its roofline.
+  per_frame     -- the same path with ONE frame per launch (what GOFPID.detect()
+                   runs), whole-step timed by the same protocol + its kernel record
+  worst_case    -- reference-test style input (i.i.d. uniform uint8 frames,
+                   /root/reference/tests/test_pipeline.py:98-109): every pixel carries
+                   all 5 modes (206 B/px/frame), nothing is ever "settled"
   cpu_baseline  -- the CPU oracle ("port" of the OpenCV algorithms, NOT OpenCV)
                    timed on this host's cores on a bounded sample
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -34,8 +58,13 @@ if ROOT not in sys.path:
 # per-frame parallel regions (read by libgomp when oracle/ is loaded)
 os.environ.setdefault("OMP_WAIT_POLICY", "active")
 
-HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
-EVENT_STRIDE = 4     # timed steps between two event-bracketed ones
+HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+N_SIMD = 1024            # 256 CUs x 4 SIMDs
+CLOCK_HZ = 2.4e9         # max shader clock
+VALU_ISSUE_CYCLES = 4    # one wave64 vector instruction per SIMD per 4 cycles (the mix of
+                         # this kernel measures 2.4-4.9, profiles/r01_valu_issue_rates.txt)
+VALU_PEAK_GINST = N_SIMD * CLOCK_HZ / VALU_ISSUE_CYCLES / 1e9
+MIN_PREROLL_FRAMES = 256
 
 
 def make_pool(torch, streams, pool, h, w, device, seed, n_objects=6):
@@ -69,6 +98,14 @@ def make_pool(torch, streams, pool, h, w, device, seed, n_objects=6):
     return frames
 
 
+def make_noise_pool(torch, streams, pool, h, w, device, seed):
+    """Reference-test style frames: np.random.randint(0, high=255) uint8, i.i.d."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    return torch.randint(0, 255, (pool, streams, h, w, 3), generator=g, device=device,
+                         dtype=torch.uint8)
+
+
 def cpu_baseline(frames_host, h, w, budget_s):
     """Time the CPU oracle on this host (checker reused as the baseline leg).
     The thread count is the best of a short sweep up to the CPUs this process
@@ -100,19 +137,123 @@ def cpu_baseline(frames_host, h, w, budget_s):
             "mean_modes": round(p.mean_modes(), 4)}
 
 
-def load_traffic(path, key):
-    """HBM bytes per launch from the committed PMC passes (profiles/), if the
-    recorded configuration matches this run; else None."""
-    # the named file, then the per-frame record kept next to it
-    for cand in (path, os.path.join(os.path.dirname(path), "r01_traffic_T1.json")):
-        try:
-            with open(cand) as f:
-                rec = json.load(f)
-            if rec.get("config") == key:
-                return rec.get("hbm_bytes_per_launch")
-        except Exception:
-            pass
-    return None
+def load_pmc(path, key):
+    """The committed PMC record (profiles/) of this configuration, or {}: HBM bytes
+    per launch (FETCH_SIZE x 2 + WRITE_SIZE, the gfx950 correction) and the SQ
+    instruction counts per launch.  Counters cannot be read inside this process;
+    they come from separate `rocprofv3 --pmc` passes of this same command."""
+    try:
+        with open(path) as f:
+            recs = json.load(f)
+    except Exception:
+        return {}
+    for rec in recs if isinstance(recs, list) else [recs]:
+        if rec.get("config") == key:
+            return rec
+    return {}
+
+
+class Runner:
+    """One pipeline + its frame pool, stepped by the protocol in the module docstring."""
+
+    def __init__(self, torch, gd, pipe, frames, masks, T, red_dev):
+        self.torch, self.gd, self.pipe = torch, gd, pipe
+        self.frames, self.masks, self.T, self.P = frames, masks, T, frames.shape[0]
+        self.red_dev = red_dev
+        self.i = 0
+
+    def step(self, T=None):
+        T = T or self.T
+        base = (self.i * T) % self.P
+        if base + T > self.P:
+            base = 0
+        self.pipe.apply_device(self.frames[base].data_ptr(), self.masks.data_ptr(), n_frames=T)
+        self.i += 1
+
+    def sync(self):
+        self.pipe.synchronize()
+        self.torch.cuda.synchronize()
+
+    def preroll(self, seconds, min_frames, T=None):
+        """Real steps until both the time and the frame count are reached (every rank
+        the same number of steps: the count is fixed by rank 0's clock in units of 16)."""
+        T = T or self.T
+        done, t0 = 0, time.perf_counter()
+        while True:
+            for _ in range(16):
+                self.step(T)
+            done += 16
+            self.sync()
+            go = 1.0 if (time.perf_counter() - t0 < seconds or done * T < min_frames) else 0.0
+            if self.gd.max_over_ranks(go, device=self.red_dev) == 0.0:
+                return done
+
+    def rounds(self, K, R, T=None):
+        """R rounds of exactly K steps -> list of per-round elapsed seconds (MAX over ranks)."""
+        out = []
+        for _ in range(R):
+            self.sync()
+            self.gd.barrier()
+            t0 = time.perf_counter()
+            for _ in range(K):
+                self.step(T)
+            self.sync()
+            out.append(self.gd.max_over_ranks(time.perf_counter() - t0, device=self.red_dev))
+        return out
+
+    def kernel_times(self, K, T=None):
+        """HIP events around the detector and the morphology kernel of K steps, on the
+        launch stream -> (detector us, morphology us, launches)."""
+        self.sync()
+        self.pipe.profile(True, K, stride=1)
+        for _ in range(K):
+            self.step(T)
+        self.sync()
+        det, morph = self.pipe.profile_read(K)
+        self.pipe.profile(False)
+        if not len(det):
+            return None, None, 0
+        # mean over the launches (what rocprofv3's per-kernel average reports)
+        return float(det.mean()) * 1e3, float(morph.mean()) * 1e3, len(det)
+
+
+def summarize_rounds(el, K, frames_per_step):
+    med = statistics.median(el)
+    return {"ms_per_step": round(med / K * 1e3, 4),
+            "frames_per_s": round(frames_per_step * K / med, 1),
+            "rounds": len(el),
+            "round_ms": {"median": round(med * 1e3, 3), "min": round(min(el) * 1e3, 3),
+                         "max": round(max(el) * 1e3, 3)}}
+
+
+def kernel_record(pipe, mbar, T, det_us, morph_us, n, pmc, kernel_name):
+    """Roofline statement of one detector launch of T frames per stream."""
+    _, launch_b = pipe.algorithmic_bytes(mbar, T)
+    t = det_us * 1e-6
+    rec = {"kernel": kernel_name, "avg_kernel_us": round(det_us, 2), "launches_timed": n,
+           "morph_kernel_us": round(morph_us, 2), "mean_modes": round(mbar, 4),
+           "algorithmic_bytes_per_launch": int(launch_b),
+           "traffic": pmc.get("hbm_bytes_per_launch")}
+    hbm = launch_b / t / 1e9
+    if T > 1:
+        insts = pmc.get("sq_insts_valu")
+        rec.update({
+            "bound": "valu-issue",
+            "achieved": round(insts / t / 1e9, 1) if insts else None,
+            "peak": round(VALU_PEAK_GINST, 1), "unit": "G wave-instr/s",
+            "frac": round(insts / t / 1e9 / VALU_PEAK_GINST, 4) if insts else None,
+            "valu_insts_per_launch": insts,
+            "valu_model": "SQ_INSTS_VALU per launch (committed PMC pass) x %d cycles / (%d SIMDs x "
+                          "%.1f GHz x t)" % (VALU_ISSUE_CYCLES, N_SIMD, CLOCK_HZ / 1e9),
+            "hbm": {"achieved": round(hbm, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(hbm / HBM_PEAK_GBS, 4),
+                    "traffic_frac": round(pmc["hbm_bytes_per_launch"] / t / 1e9 / HBM_PEAK_GBS, 4)
+                    if pmc.get("hbm_bytes_per_launch") else None},
+        })
+    else:
+        rec.update({"bound": "hbm", "achieved": round(hbm, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(hbm / HBM_PEAK_GBS, 4)})
+    return rec
 
 
 def main():
@@ -120,10 +261,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=256)
     ap.add_argument("--warmup", type=int, default=64)
+    ap.add_argument("--rounds", type=int, default=10, help="timed rounds of --steps steps; the median is reported")
+    ap.add_argument("--preroll-seconds", type=float, default=0.5)
     ap.add_argument("--streams", type=int, default=8, help="video streams stepped per GPU")
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--pool", type=int, default=32, help="distinct synthetic frames per stream")
+    ap.add_argument("--pool", type=int, default=256, help="distinct synthetic frames per stream")
     ap.add_argument("--frames-per-step", type=int, default=8,
                     help="consecutive frames of every stream handed over per step (temporal "
                          "blocking: the MOG2 model crosses HBM once per 8 frames)")
@@ -131,9 +274,11 @@ def main():
     ap.add_argument("--morph", default="erode5,dilate5",
                     help="mat_morph list, e.g. erode7,dilate7,dilate7,erode7 (BASELINE config 3)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="0 disables the CPU leg")
-    ap.add_argument("--traffic-file", default=os.path.join(ROOT, "profiles", "traffic_latest.json"))
+    ap.add_argument("--pmc-file", default=os.path.join(ROOT, "profiles", "pmc_latest.json"))
     ap.add_argument("--no-events", action="store_true",
-                    help="do not bracket kernels with HIP events (roofline block omitted)")
+                    help="no HIP-event rounds (roofline blocks omitted); what the rocprofv3 passes run")
+    ap.add_argument("--no-extra", action="store_true", help="skip the per-frame and worst-case blocks")
+    ap.add_argument("--noise", action="store_true", help="main workload on the worst-case input instead")
     args = ap.parse_args()
 
     import torch
@@ -156,92 +301,62 @@ def main():
     gd.init(backend=backend, device=device if backend == "nccl" else None)   # no-op for 1 process
     red_dev = device if backend == "nccl" else "cpu"
 
+    import numpy as np
+
     from pygofpid_amd import _lib
     from pygofpid_amd.foreground import ForegroundPipeline
 
-    h, w, S, K, W = args.height, args.width, args.streams, args.steps, args.warmup
+    h, w, S, K, W, R = args.height, args.width, args.streams, args.steps, args.warmup, max(1, args.rounds)
     T = args.frames_per_step
     if T < 1 or args.pool % T:
         raise SystemExit("--frames-per-step must divide --pool")
-    frames = make_pool(torch, S, args.pool, h, w, device, seed=17 + rank, n_objects=args.objects)
-    masks = torch.empty((T, S, h, w), dtype=torch.uint8, device=device)
-    torch.cuda.synchronize()
-
-    ctx = _lib.Context(dev_index)
-    import numpy as np
     morph = []
     for item in [m for m in args.morph.split(",") if m]:
         op = "erode" if item.startswith("erode") else "dilate"
         kk = int(item[len(op):])
         morph.append((op, np.ones((kk, kk), np.uint8)))
+    ctx = _lib.Context(dev_index)
+    if args.noise:
+        frames = make_noise_pool(torch, S, args.pool, h, w, device, seed=17 + rank)
+    else:
+        frames = make_pool(torch, S, args.pool, h, w, device, seed=17 + rank, n_objects=args.objects)
+    masks = torch.empty((max(T, 8), S, h, w), dtype=torch.uint8, device=device)
+    torch.cuda.synchronize()
     pipe = ForegroundPipeline((h, w, 3), streams=S, ctx=ctx, morph=morph)
-    P = args.pool
+    run = Runner(torch, gd, pipe, frames, masks, T, red_dev)
 
-    def barrier():
-        pipe.synchronize()
-        torch.cuda.synchronize()
-        gd.barrier()
-
-    def step(i):   # frames [iT, iT+T) of every stream, consecutive in the pool
-        pipe.apply_device(frames[(i * T) % P].data_ptr(), masks.data_ptr(), n_frames=T)
-
-    for t in range(W):
-        step(t)
-    barrier()
+    # 1-3: pre-roll, warm-up, timed rounds
+    pre_steps = run.preroll(args.preroll_seconds, MIN_PREROLL_FRAMES)
+    for _ in range(W):
+        run.step()
     mbar_start = pipe.mean_modes()
-    if not args.no_events:
-        # HIP events around the kernels of every EVENT_STRIDE-th timed step (each record
-        # costs the stream a few microseconds; a sample keeps that off `value`)
-        pipe.profile(True, K, stride=EVENT_STRIDE)
-    barrier()
     if os.environ.get("GOF_ABLATE_TIMED"):          # profiles/ ablations: flip after the warm-up
         os.environ["GOF_ABLATE"] = os.environ["GOF_ABLATE_TIMED"]
-    t0 = time.perf_counter()
-    for t in range(W, W + K):
-        step(t)
-    pipe.synchronize()
-    torch.cuda.synchronize()
-    gd.barrier()
-    elapsed = gd.max_over_ranks(time.perf_counter() - t0, device=red_dev)
+    el = run.rounds(K, R)
+    main_sum = summarize_rounds(el, K, S * T * world)
+    mbar = 0.5 * (mbar_start + pipe.mean_modes())
+    fg = float((masks[:T] != 0).float().mean().item())
 
-    det_ms = morph_ms = 0.0
+    # 4: kernel times, outside the timed rounds
+    det_us = morph_us = None
     n_meas = 0
     if not args.no_events:
-        det_ms, morph_ms, n_meas = pipe.profile_query()
-        pipe.profile(False)
-    mbar_end = pipe.mean_modes()
-    mbar = 0.5 * (mbar_start + mbar_end)
-    fg = float((masks != 0).float().mean().item())
+        det_us, morph_us, n_meas = run.kernel_times(min(2 * K, 512))
 
-    # outside the timed region: the same kernel in its one-frame-per-launch form
-    # (what GOFPID.detect() runs, and the HBM-bound form of the kernel), for the record
-    single = None
-    if T > 1 and not args.no_events:
-        n1 = 32
-        pipe.profile(True, n1)
-        for t in range(n1):
-            pipe.apply_device(frames[t % P].data_ptr(), masks.data_ptr(), n_frames=1)
-        pipe.synchronize()
-        d1, m1, c1 = pipe.profile_query()
-        pipe.profile(False)
-        if c1:
-            _, b1 = pipe.algorithmic_bytes(pipe.mean_modes(), 1)
-            s1 = d1 / c1 * 1e-3
-            single = {"avg_kernel_us": round(s1 * 1e6, 2), "achieved": round(b1 / s1 / 1e9, 1),
-                      "frac": round(b1 / s1 / 1e9 / HBM_PEAK_GBS, 4),
-                      "algorithmic_bytes_per_launch": int(b1), "launches_timed": c1,
-                      "morph_kernel_us": round(m1 / c1 * 1e3, 2)}
-
+    morph_txt = " -> ".join("%s %dx%d" % (o, k.shape[0], k.shape[1]) for o, k in morph) or "no morphology"
+    scene = ("i.i.d. uniform uint8 frames (reference-test style worst case)" if args.noise else
+             "synthetic surveillance scene, %d moving objects with shadows per stream, %d-frame pool"
+             % (args.objects, args.pool))
+    out = None
     if rank == 0:
-        total_frames = S * T * K * world
         out = {
             "metric": "frames/sec at 1080p MOG2+5x5 morph",
-            "value": round(total_frames / elapsed, 1),
+            "value": main_sum["frames_per_s"],
             "unit": "frames/s",
             "n_gpus": world,
             "steps": K,
             "warmup": W,
-            "ms_per_step": round(elapsed / K * 1e3, 4),
+            "ms_per_step": main_sum["ms_per_step"],
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -249,55 +364,85 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "%dx%d BGR uint8, GaussianBlur 3x3 (sigma 4) -> MOG2 (cv2 defaults, "
-                            "shadows on) -> %s; %d streams per GPU, %d "
-                            "consecutive frame(s) per stream per step; frames resident in HBM"
-                            % (w, h, " -> ".join("%s %dx%d" % (o, k.shape[0], k.shape[1]) for o, k in morph)
-                               or "no morphology", S, T),
+                            "shadows on) -> %s; %d streams per GPU, %d consecutive frame(s) per "
+                            "stream per step; %s; frames resident in HBM"
+                            % (w, h, morph_txt, S, T, scene),
                 "streams_per_gpu": S, "frames_per_stream_per_step": T,
                 "frames_per_step": S * T * world, "height": h, "width": w,
                 "channels": 3, "mean_modes": round(mbar, 4), "foreground_fraction": round(fg, 5),
                 "parallelism": "streams sharded %d per GPU, no data-path collective" % S,
             },
+            "protocol": {"preroll_steps": pre_steps, "preroll_frames_per_stream": pre_steps * T,
+                         "rounds": R, "round_ms": main_sum["round_ms"],
+                         "statistic": "median round of K steps; MAX over ranks per round"},
         }
         if n_meas:
-            # per-unit figure B_px = C + 1 + 2(1 + 4(2+C) m) bytes per
-            # pixel-frame (model read + written once per frame) x the pixel-frames
-            # one launch processes.  With T frames per launch the kernel moves the
-            # model once per launch, so it can exceed this single-frame roofline;
-            # its own byte count is reported next to it.
+            key = {"streams": S, "height": h, "width": w, "frames_per_step": T,
+                   "input": "noise" if args.noise else "scene"}
+            name = ("mog2_frames_kernel<3> (fused 3x3 blur + MOG2 update + classify, %d frames per launch)"
+                    % min(T, 8)) if T > 1 else \
+                "mog2_kernel<3,true,false,true> (fused 3x3 blur + MOG2 update + classify, 1 frame per launch)"
+            roof = kernel_record(pipe, mbar, T, det_us, morph_us, n_meas, load_pmc(args.pmc_file, key), name)
             _, per_frame_b = pipe.algorithmic_bytes(mbar, 1)
-            total_b, launch_b = pipe.algorithmic_bytes(mbar, T)
-            det_s = det_ms / n_meas * 1e-3
-            unit_b = per_frame_b * T
-            achieved = unit_b / det_s / 1e9
-            key = {"streams": S, "height": h, "width": w, "frames_per_step": T}
-            out["roofline"] = {
-                "bound": "hbm",
-                "kernel": "%s (fused 3x3 blur + MOG2 update + classify, %d frame(s) per launch)"
-                          % ("mog2_frames_kernel<3>" if T > 1 else "mog2_kernel<3,true,false,true>",
-                             min(T, 8)),
-                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": load_traffic(args.traffic_file, key),
-                "algorithmic_bytes_per_launch": int(unit_b),
-                "bytes_per_pixel_frame": round(per_frame_b / (S * h * w), 3),
-                "pixel_frames_per_launch": S * T * h * w,
-                "avg_kernel_us": round(det_s * 1e6, 2),
-                "launches_timed": n_meas,
-                "temporal_blocking": {
-                    "frames_per_launch": T,
-                    "launch_bytes_model_once": int(launch_b),
-                    "achieved_on_launch_bytes_GBps": round(launch_b / det_s / 1e9, 1),
-                    "note": "T frames per launch keep the per-pixel model in registers; 'achieved' "
-                            "prices every frame at the single-frame algorithmic bytes (SURVEY 8d), "
-                            "so frac > 1 means the kernel beats the one-frame-per-pass HBM roofline",
-                } if T > 1 else None,
-                "per_frame_launch": single,
-                "morph_kernel_us": round(morph_ms / n_meas * 1e3, 2),
-                "whole_step_GBps": round(total_b / (elapsed / K) / 1e9, 1),
-            }
+            roof["kernels_us_per_step"] = round(det_us + morph_us, 2)
+            roof["step_us"] = round(main_sum["ms_per_step"] * 1e3, 2)
+            if T > 1:
+                # NOT a roofline: what one-frame-per-pass traffic (6 + 40 m B/px/frame)
+                # would have needed at the HBM peak, over what the launch took
+                roof["speedup_vs_one_frame_per_pass_at_hbm_peak"] = round(
+                    per_frame_b * T / (HBM_PEAK_GBS * 1e9) / (det_us * 1e-6), 3)
+            out["roofline"] = roof
+
+    # the drop-in form: ONE frame per launch, same pipeline (model trained by the above)
+    if not args.no_extra and T > 1 and not args.no_events:
+        run.preroll(0.1, 32, T=1)
+        el1 = run.rounds(K, R, T=1)
+        d1, m1, n1 = run.kernel_times(min(2 * K, 256), T=1)
+        if rank == 0 and n1:
+            s1 = summarize_rounds(el1, K, S * world)
+            mb1 = pipe.mean_modes()
+            key = {"streams": S, "height": h, "width": w, "frames_per_step": 1,
+                   "input": "noise" if args.noise else "scene"}
+            rec = kernel_record(pipe, mb1, 1, d1, m1, n1, load_pmc(args.pmc_file, key),
+                                "mog2_kernel<3,true,false,true> (1 frame per launch: what GOFPID.detect() runs)")
+            rec.update({"value": s1["frames_per_s"], "unit_value": "frames/s",
+                        "ms_per_step": s1["ms_per_step"], "round_ms": s1["round_ms"],
+                        "frames_per_step": S * world})
+            out["per_frame"] = rec
+
+    # worst case: uniform-noise input, every pixel carries all five modes
+    if not args.no_extra and not args.noise and world == 1 and not args.no_events:
+        del run, pipe
+        npool = 64
+        nframes = make_noise_pool(torch, S, npool, h, w, device, seed=99)
+        npipe = ForegroundPipeline((h, w, 3), streams=S, ctx=ctx, morph=morph)
+        nrun = Runner(torch, gd, npipe, nframes, masks, T, red_dev)
+        nrun.preroll(0.3, MIN_PREROLL_FRAMES)
+        Kn = max(4, min(K, 64))
+        eln = nrun.rounds(Kn, R)
+        dn, mn, nn = nrun.kernel_times(Kn)
+        sn = summarize_rounds(eln, Kn, S * T)
+        mbn = npipe.mean_modes()
+        key = {"streams": S, "height": h, "width": w, "frames_per_step": T, "input": "noise"}
+        rec = kernel_record(npipe, mbn, T, dn, mn, nn, load_pmc(args.pmc_file, key),
+                            "mog2_frames_kernel<3>, general five-mode loop" if T > 1 else "mog2_kernel<3,true,false,true>")
+        rec.update({"input": "i.i.d. uniform uint8 frames, randint(0, 255) "
+                             "(/root/reference/tests/test_pipeline.py:98-109 style), %d-frame pool" % npool,
+                    "value": sn["frames_per_s"], "unit_value": "frames/s", "steps": Kn,
+                    "ms_per_step": sn["ms_per_step"], "round_ms": sn["round_ms"],
+                    "foreground_fraction": round(float((masks[:T] != 0).float().mean().item()), 5)})
+        if T > 1:
+            nrun.preroll(0.05, 16, T=1)
+            d1, m1, n1 = nrun.kernel_times(32, T=1)
+            key1 = dict(key, frames_per_step=1)
+            rec["per_frame"] = kernel_record(npipe, npipe.mean_modes(), 1, d1, m1, n1,
+                                             load_pmc(args.pmc_file, key1), "mog2_kernel<3,true,false,true>")
+        out["worst_case"] = rec
+        del nrun, npipe, nframes
+
+    if rank == 0:
         if args.cpu_seconds > 0 and world == 1:   # CPU leg: rank 0 at N = 1 only
-            host = [frames[i, 0].cpu().numpy() for i in range(P)]
+            host = [frames[i, 0].cpu().numpy() for i in range(min(32, frames.shape[0]))]
             out["cpu_baseline"] = cpu_baseline(host, h, w, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     if world > 1:

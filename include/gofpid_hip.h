@@ -233,6 +233,11 @@ int gof_pipeline_profile_enable(gof_pipeline *p, int enable, int capacity);
 int gof_pipeline_profile_stride(gof_pipeline *p, int stride);
 int gof_pipeline_profile_query(gof_pipeline *p, double *detector_ms, double *morph_ms,
                                int *n_applies);
+/* The same record apply by apply: fills detector_ms[i] / morph_ms[i] for the first
+ * min(capacity, measured) applies, returns the number measured in *n_applies and
+ * clears the record (per-launch series: medians, ramps). */
+int gof_pipeline_profile_read(gof_pipeline *p, float *detector_ms, float *morph_ms, int capacity,
+                              int *n_applies);
 
 #ifdef __cplusplus
 }

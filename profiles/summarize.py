@@ -1,5 +1,13 @@
-"""Condenses rocprofv3 CSV output (kernel trace + PMC passes) into a short text
-summary and a traffic JSON that bench.py can cite.  usage: summarize.py <dir> [frames_per_step]"""
+"""Condenses rocprofv3 CSV output (kernel trace + PMC passes) of one bench.py
+configuration into a short text summary and a PMC record that bench.py cites
+(profiles/pmc_latest.json holds one record per configuration).
+
+    summarize.py <dir> <frames_per_step> <scene|noise> <timed dispatches> [streams h w]
+
+<dir> holds trace/ (--kernel-trace) and pmc_*/ (one --pmc pass each).  The timed
+region of a `bench.py --no-events --no-extra` run is its LAST rounds x steps
+dispatches of the detector kernel.
+"""
 import csv
 import glob
 import json
@@ -20,57 +28,72 @@ def short(name):
     return name.split("(")[0][:70]
 
 
-def main(d, fps=8):
-    # kernel trace: durations per kernel
+def main(d, fps, inp, timed, streams=8, h=1080, w=1920):
+    # kernel trace: durations per kernel, in dispatch order
     dur = defaultdict(list)
-    for r in rows(os.path.join(d, "trace", "**", "*kernel_trace.csv")):
+    trace = sorted(rows(os.path.join(d, "trace", "**", "*kernel_trace.csv")),
+                   key=lambda r: int(r["Start_Timestamp"]))
+    for r in trace:
         dur[short(r["Kernel_Name"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-    print("== kernel trace (ns) ==")
+    print("== kernel trace (ns), whole process ==")
     tot = sum(sum(v) for v in dur.values()) or 1
-    for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
+    for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1]))[:8]:
         v2 = sorted(v)
         print("%-70s calls %5d  avg %10.1f  med %10.1f  min %10d  max %10d  %5.1f%%"
               % (k, len(v), sum(v) / len(v), v2[len(v) // 2], v2[0], v2[-1], 100.0 * sum(v) / tot))
-    print("== timed region only (the last 256 dispatches = bench.py's K steps) ==")
+    print("== timed region only (the last %d dispatches = bench.py's rounds x steps) ==" % timed)
+    timed_avg = {}
     for k, v in dur.items():
-        if ("mog2" in k or "morph" in k) and len(v) >= 256:
-            t = v[-256:]
-            print("%-70s avg %10.1f ns over %d dispatches" % (k, sum(t) / len(t), len(t)))
-    # PMC: average per dispatch per kernel
+        if ("mog2" in k or "morph" in k or "fd_" in k) and len(v) >= timed:
+            t = v[-timed:]
+            timed_avg[k] = sum(t) / len(t)
+            print("%-70s avg %10.1f ns  med %10.1f  over %d dispatches"
+                  % (k, timed_avg[k], sorted(t)[len(t) // 2], len(t)))
+    # PMC: mean per dispatch per kernel over the last `timed` dispatches
     pmc = defaultdict(lambda: defaultdict(list))
     for sub in sorted(glob.glob(os.path.join(d, "pmc_*"))):
         if not os.path.isdir(sub):
             continue
         for r in rows(os.path.join(sub, "**", "*counter_collection.csv")):
             pmc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    print("\n== PMC (mean per dispatch) ==")
+    print("\n== PMC (mean per dispatch over the timed region) ==")
     out = {}
     for k, cs in pmc.items():
         if "mog2" not in k and "morph" not in k:
             continue
         print(k)
         for c, v in sorted(cs.items()):
-            # skip warm-up dispatches: use the last half
-            v = v[len(v) // 2:]
+            v = v[-timed:] if len(v) >= timed else v[len(v) // 2:]
             m = sum(v) / len(v)
             out.setdefault(k, {})[c] = m
             print("    %-28s %16.1f   (n=%d)" % (c, m, len(v)))
+    rec = None
     for k, cs in out.items():
         if "mog2" in k and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
             # MI355X_MICROARCH.md HBM: counters are in KiB; on gfx950 FETCH_SIZE
-            # reports 1/2 of the bytes of a wide coalesced streaming read -> x2.
+            # reports 1/2 of the bytes of a wide coalesced streaming read -> x2
+            # (re-calibrated for dword-per-lane streams, profiles/r01_counter_calibration.txt)
             fetch_raw = cs["FETCH_SIZE"] * 1024.0
             write = cs["WRITE_SIZE"] * 1024.0
-            rec = {"config": {"streams": 8, "height": 1080, "width": 1920, "frames_per_step": fps},
+            rec = {"config": {"streams": streams, "height": h, "width": w, "frames_per_step": fps,
+                              "input": inp},
                    "kernel": k, "fetch_size_raw_bytes": fetch_raw, "fetch_bytes_corrected": 2 * fetch_raw,
                    "write_bytes": write, "hbm_bytes_per_launch": 2 * fetch_raw + write,
-                   "note": "per launch, mean of the last half of the dispatches; FETCH_SIZE x2 per "
-                           "MI355X_MICROARCH.md (gfx950 tallies 128-B requests as 64 B), factor "
-                           "re-calibrated for 4-B/lane streams in profiles/r01_counter_calibration.txt"}
-            print("\ntraffic:", json.dumps(rec))
-            with open(os.path.join(d, "traffic.json"), "w") as f:
+                   "sq_insts_valu": cs.get("SQ_INSTS_VALU"), "sq_insts_salu": cs.get("SQ_INSTS_SALU"),
+                   "sq_busy_cycles": cs.get("SQ_BUSY_CYCLES"), "sq_waves": cs.get("SQ_WAVES"),
+                   "kernel_trace_avg_ns": timed_avg.get(k),
+                   "note": "means per launch over the timed region; FETCH_SIZE x2 per MI355X_MICROARCH.md "
+                           "(gfx950 tallies 128-B requests as 64 B)"}
+            if cs.get("SQ_INSTS_VALU") and timed_avg.get(k):
+                t = timed_avg[k] * 1e-9
+                rec["valu_issue_frac"] = cs["SQ_INSTS_VALU"] * 4 / (1024 * 2.4e9 * t)
+                rec["hbm_traffic_GBps"] = rec["hbm_bytes_per_launch"] / t / 1e9
+            print("\npmc record:", json.dumps(rec))
+            with open(os.path.join(d, "pmc.json"), "w") as f:
                 json.dump(rec, f)
+    return rec
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 8)
+    a = sys.argv
+    main(a[1], int(a[2]), a[3], int(a[4]), *[int(x) for x in a[5:8]])

@@ -1199,6 +1199,24 @@ int gof_pipeline_profile_query(gof_pipeline *p, double *detector_ms, double *mor
     return GOF_OK;
 }
 
+int gof_pipeline_profile_read(gof_pipeline *p, float *detector_ms, float *morph_ms, int capacity,
+                              int *n_applies)
+{
+    if (!p || !detector_ms || !morph_ms || !n_applies || capacity < 0)
+        return fail(GOF_EINVAL, "bad argument");
+    GOF_HIP(hipSetDevice(p->ctx->device));
+    for (size_t i = 0; i < p->prof_used; i++) {
+        GOF_HIP(hipEventSynchronize(p->events[3 * i + 2]));
+        if (i >= (size_t)capacity)
+            continue;
+        GOF_HIP(hipEventElapsedTime(&detector_ms[i], p->events[3 * i], p->events[3 * i + 1]));
+        GOF_HIP(hipEventElapsedTime(&morph_ms[i], p->events[3 * i + 1], p->events[3 * i + 2]));
+    }
+    *n_applies = (int)p->prof_used;
+    p->prof_used = 0;
+    return GOF_OK;
+}
+
 int gof_pipeline_mean_modes(gof_pipeline *p, double *mean_modes)
 {
     if (!p || !mean_modes)

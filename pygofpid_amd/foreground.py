@@ -153,6 +153,16 @@ class ForegroundPipeline:
                                                           C.byref(n)))
         return a.value, b.value, n.value
 
+    def profile_read(self, capacity):
+        """-> (detector-kernel ms, morphology-kernel ms) arrays, one entry per measured step"""
+        a, b, n = np.zeros(capacity, np.float32), np.zeros(capacity, np.float32), C.c_int()
+        f32 = C.POINTER(C.c_float)
+        _lib.check(_lib.load().gof_pipeline_profile_read(self._h, a.ctypes.data_as(f32),
+                                                         b.ctypes.data_as(f32), int(capacity),
+                                                         C.byref(n)))
+        k = min(n.value, capacity)
+        return a[:k], b[:k]
+
     def mog2_state(self):
         """Export the model planes (host copies) -- parity tests / checkpoint."""
         m = _lib.load().gof_pipeline_mog2(self._h)
