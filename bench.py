@@ -31,8 +31,12 @@ Prints ONE JSON line on rank 0, with
   roofline      -- the dominant kernel (fused blur + MOG2) against the roofline that
                    bounds it.  8 frames per launch: vector-instruction issue (the
                    model crosses HBM once per 8 frames, so memory is out of the way):
-                   frac = SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x 2.4 GHz x t), with
-                   SQ_INSTS_VALU from the committed PMC pass of this configuration;
+                   achieved = SQ_INSTS_VALU / t (from the committed PMC pass of this
+                   configuration), peak = 1024 SIMDs x 2.4 GHz / 2 cycles (a SIMD-32
+                   takes two cycles per wave64 instruction: the 157 TFLOP/s fp32 rate);
+                   `cycles_per_valu_inst` next to it is what the mix of this kernel
+                   (64-bit encodings: v_dot4, v_mad_u32_u24, v_cndmask_e64 at 4.2-4.9
+                   cycles each, profiles/r01_valu_issue_rates.txt) actually costs;
                    `hbm` = the launch's own algorithmic bytes / t against 8 TB/s.
                    1 frame per launch: HBM (algorithmic bytes / t / 8 TB/s).
                    Every frac is <= 1 by construction of its roofline.
@@ -61,8 +65,8 @@ os.environ.setdefault("OMP_WAIT_POLICY", "active")
 HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 N_SIMD = 1024            # 256 CUs x 4 SIMDs
 CLOCK_HZ = 2.4e9         # max shader clock
-VALU_ISSUE_CYCLES = 4    # one wave64 vector instruction per SIMD per 4 cycles (the mix of
-                         # this kernel measures 2.4-4.9, profiles/r01_valu_issue_rates.txt)
+VALU_ISSUE_CYCLES = 2    # a SIMD-32 issues one wave64 vector instruction per 2 cycles at best
+                         # (measured per opcode: 2.4-4.9, profiles/r01_valu_issue_rates.txt)
 VALU_PEAK_GINST = N_SIMD * CLOCK_HZ / VALU_ISSUE_CYCLES / 1e9
 MIN_PREROLL_FRAMES = 256
 
@@ -201,20 +205,36 @@ class Runner:
             out.append(self.gd.max_over_ranks(time.perf_counter() - t0, device=self.red_dev))
         return out
 
-    def kernel_times(self, K, T=None):
+    def kernel_times(self, K, step_us, T=None):
         """HIP events around the detector and the morphology kernel of K steps, on the
-        launch stream -> (detector us, morphology us, launches)."""
+        launch stream.  The events are created beforehand and 32 un-bracketed steps run
+        first, without a host synchronisation in between (an idle gap costs the first
+        ~30 launches their clocks, profiles/r02_clock_ramp.json).  An event marker
+        serialises the stream: three per step lengthen the step by 3 d, one d inside each
+        bracket; d = (bracketed period - un-bracketed period `step_us`) / 3 is taken off
+        both kernels' raw means.  -> dict or None."""
+        self.pipe.profile(True, K, stride=1)      # creates the events
+        self.pipe.profile(False)
         self.sync()
+        for _ in range(32):
+            self.step(T)
         self.pipe.profile(True, K, stride=1)
         for _ in range(K):
             self.step(T)
         self.sync()
+        span_us = self.pipe.profile_span() * 1e3
         det, morph = self.pipe.profile_read(K)
         self.pipe.profile(False)
-        if not len(det):
-            return None, None, 0
-        # mean over the launches (what rocprofv3's per-kernel average reports)
-        return float(det.mean()) * 1e3, float(morph.mean()) * 1e3, len(det)
+        n = len(det)
+        if not n:
+            return None
+        det_raw, morph_raw = float(det.mean()) * 1e3, float(morph.mean()) * 1e3
+        # span covers n brackets and n - 1 gaps
+        period = (span_us + (span_us - n * (det_raw + morph_raw)) / max(1, n - 1)) / n
+        d = max(0.0, (period - step_us) / 3.0)
+        return {"det_us": det_raw - d, "morph_us": morph_raw - d, "n": n, "det_raw_us": det_raw,
+                "morph_raw_us": morph_raw, "marker_us": d,
+                "det_median_raw_us": float(statistics.median(det.tolist())) * 1e3}
 
 
 def summarize_rounds(el, K, frames_per_step):
@@ -226,12 +246,18 @@ def summarize_rounds(el, K, frames_per_step):
                          "max": round(max(el) * 1e3, 3)}}
 
 
-def kernel_record(pipe, mbar, T, det_us, morph_us, n, pmc, kernel_name):
-    """Roofline statement of one detector launch of T frames per stream."""
+def kernel_record(pipe, mbar, T, kt, pmc, kernel_name):
+    """Roofline statement of one detector launch of T frames per stream (kt: Runner.kernel_times)."""
     _, launch_b = pipe.algorithmic_bytes(mbar, T)
+    det_us, morph_us = kt["det_us"], kt["morph_us"]
     t = det_us * 1e-6
-    rec = {"kernel": kernel_name, "avg_kernel_us": round(det_us, 2), "launches_timed": n,
-           "morph_kernel_us": round(morph_us, 2), "mean_modes": round(mbar, 4),
+    rec = {"kernel": kernel_name, "avg_kernel_us": round(det_us, 2), "launches_timed": kt["n"],
+           "morph_kernel_us": round(morph_us, 2),
+           "event_timing": {"raw_avg_kernel_us": round(kt["det_raw_us"], 2),
+                            "raw_median_kernel_us": round(kt["det_median_raw_us"], 2),
+                            "raw_morph_kernel_us": round(kt["morph_raw_us"], 2),
+                            "marker_overhead_us": round(kt["marker_us"], 2)},
+           "mean_modes": round(mbar, 4),
            "algorithmic_bytes_per_launch": int(launch_b),
            "traffic": pmc.get("hbm_bytes_per_launch")}
     hbm = launch_b / t / 1e9
@@ -243,8 +269,11 @@ def kernel_record(pipe, mbar, T, det_us, morph_us, n, pmc, kernel_name):
             "peak": round(VALU_PEAK_GINST, 1), "unit": "G wave-instr/s",
             "frac": round(insts / t / 1e9 / VALU_PEAK_GINST, 4) if insts else None,
             "valu_insts_per_launch": insts,
-            "valu_model": "SQ_INSTS_VALU per launch (committed PMC pass) x %d cycles / (%d SIMDs x "
-                          "%.1f GHz x t)" % (VALU_ISSUE_CYCLES, N_SIMD, CLOCK_HZ / 1e9),
+            "cycles_per_valu_inst": round(N_SIMD * CLOCK_HZ * t / insts, 2) if insts else None,
+            "valu_model": "achieved = SQ_INSTS_VALU per launch (committed PMC pass, %s) / t; peak = %d "
+                          "SIMDs x %.1f GHz / %d cycles per wave64 instruction; measured issue cost "
+                          "of this kernel's opcodes: 2.4 (32-bit encodings) to 4.9 (v_dot4) cycles"
+                          % (pmc.get("source", "-"), N_SIMD, CLOCK_HZ / 1e9, VALU_ISSUE_CYCLES),
             "hbm": {"achieved": round(hbm, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(hbm / HBM_PEAK_GBS, 4),
                     "traffic_frac": round(pmc["hbm_bytes_per_launch"] / t / 1e9 / HBM_PEAK_GBS, 4)
@@ -338,10 +367,9 @@ def main():
     fg = float((masks[:T] != 0).float().mean().item())
 
     # 4: kernel times, outside the timed rounds
-    det_us = morph_us = None
-    n_meas = 0
+    kt = None
     if not args.no_events:
-        det_us, morph_us, n_meas = run.kernel_times(min(2 * K, 512))
+        kt = run.kernel_times(max(32, min(2 * K, 512)), main_sum["ms_per_step"] * 1e3)
 
     morph_txt = " -> ".join("%s %dx%d" % (o, k.shape[0], k.shape[1]) for o, k in morph) or "no morphology"
     scene = ("i.i.d. uniform uint8 frames (reference-test style worst case)" if args.noise else
@@ -376,15 +404,16 @@ def main():
                          "rounds": R, "round_ms": main_sum["round_ms"],
                          "statistic": "median round of K steps; MAX over ranks per round"},
         }
-        if n_meas:
+        if kt:
             key = {"streams": S, "height": h, "width": w, "frames_per_step": T,
                    "input": "noise" if args.noise else "scene"}
             name = ("mog2_frames_kernel<3> (fused 3x3 blur + MOG2 update + classify, %d frames per launch)"
                     % min(T, 8)) if T > 1 else \
                 "mog2_kernel<3,true,false,true> (fused 3x3 blur + MOG2 update + classify, 1 frame per launch)"
-            roof = kernel_record(pipe, mbar, T, det_us, morph_us, n_meas, load_pmc(args.pmc_file, key), name)
+            roof = kernel_record(pipe, mbar, T, kt, load_pmc(args.pmc_file, key), name)
             _, per_frame_b = pipe.algorithmic_bytes(mbar, 1)
-            roof["kernels_us_per_step"] = round(det_us + morph_us, 2)
+            det_us = kt["det_us"]
+            roof["kernels_us_per_step"] = round(kt["det_us"] + kt["morph_us"], 2)
             roof["step_us"] = round(main_sum["ms_per_step"] * 1e3, 2)
             if T > 1:
                 # NOT a roofline: what one-frame-per-pass traffic (6 + 40 m B/px/frame)
@@ -397,13 +426,13 @@ def main():
     if not args.no_extra and T > 1 and not args.no_events:
         run.preroll(0.1, 32, T=1)
         el1 = run.rounds(K, R, T=1)
-        d1, m1, n1 = run.kernel_times(min(2 * K, 256), T=1)
-        if rank == 0 and n1:
-            s1 = summarize_rounds(el1, K, S * world)
+        s1 = summarize_rounds(el1, K, S * world)
+        kt1 = run.kernel_times(max(32, min(2 * K, 256)), s1["ms_per_step"] * 1e3, T=1)
+        if rank == 0 and kt1:
             mb1 = pipe.mean_modes()
             key = {"streams": S, "height": h, "width": w, "frames_per_step": 1,
                    "input": "noise" if args.noise else "scene"}
-            rec = kernel_record(pipe, mb1, 1, d1, m1, n1, load_pmc(args.pmc_file, key),
+            rec = kernel_record(pipe, mb1, 1, kt1, load_pmc(args.pmc_file, key),
                                 "mog2_kernel<3,true,false,true> (1 frame per launch: what GOFPID.detect() runs)")
             rec.update({"value": s1["frames_per_s"], "unit_value": "frames/s",
                         "ms_per_step": s1["ms_per_step"], "round_ms": s1["round_ms"],
@@ -420,11 +449,11 @@ def main():
         nrun.preroll(0.3, MIN_PREROLL_FRAMES)
         Kn = max(4, min(K, 64))
         eln = nrun.rounds(Kn, R)
-        dn, mn, nn = nrun.kernel_times(Kn)
         sn = summarize_rounds(eln, Kn, S * T)
+        ktn = nrun.kernel_times(max(32, Kn), sn["ms_per_step"] * 1e3)
         mbn = npipe.mean_modes()
         key = {"streams": S, "height": h, "width": w, "frames_per_step": T, "input": "noise"}
-        rec = kernel_record(npipe, mbn, T, dn, mn, nn, load_pmc(args.pmc_file, key),
+        rec = kernel_record(npipe, mbn, T, ktn, load_pmc(args.pmc_file, key),
                             "mog2_frames_kernel<3>, general five-mode loop" if T > 1 else "mog2_kernel<3,true,false,true>")
         rec.update({"input": "i.i.d. uniform uint8 frames, randint(0, 255) "
                              "(/root/reference/tests/test_pipeline.py:98-109 style), %d-frame pool" % npool,
@@ -433,9 +462,10 @@ def main():
                     "foreground_fraction": round(float((masks[:T] != 0).float().mean().item()), 5)})
         if T > 1:
             nrun.preroll(0.05, 16, T=1)
-            d1, m1, n1 = nrun.kernel_times(32, T=1)
+            eln1 = nrun.rounds(Kn, 3, T=1)
+            kn1 = nrun.kernel_times(32, summarize_rounds(eln1, Kn, S)["ms_per_step"] * 1e3, T=1)
             key1 = dict(key, frames_per_step=1)
-            rec["per_frame"] = kernel_record(npipe, npipe.mean_modes(), 1, d1, m1, n1,
+            rec["per_frame"] = kernel_record(npipe, npipe.mean_modes(), 1, kn1,
                                              load_pmc(args.pmc_file, key1), "mog2_kernel<3,true,false,true>")
         out["worst_case"] = rec
         del nrun, npipe, nframes

@@ -233,6 +233,11 @@ int gof_pipeline_profile_enable(gof_pipeline *p, int enable, int capacity);
 int gof_pipeline_profile_stride(gof_pipeline *p, int stride);
 int gof_pipeline_profile_query(gof_pipeline *p, double *detector_ms, double *morph_ms,
                                int *n_applies);
+/* Elapsed ms from the first bracketed apply's first event to the last one's last
+ * event (with the number of applies: the period of an apply in bracketed mode, which
+ * minus the un-bracketed period is what the event markers themselves cost).  Call
+ * before profile_query / profile_read, which clear the record. */
+int gof_pipeline_profile_span(gof_pipeline *p, double *span_ms);
 /* The same record apply by apply: fills detector_ms[i] / morph_ms[i] for the first
  * min(capacity, measured) applies, returns the number measured in *n_applies and
  * clears the record (per-launch series: medians, ramps). */

@@ -86,7 +86,8 @@ def main(d, fps, inp, timed, streams=8, h=1080, w=1920):
                            "(gfx950 tallies 128-B requests as 64 B)"}
             if cs.get("SQ_INSTS_VALU") and timed_avg.get(k):
                 t = timed_avg[k] * 1e-9
-                rec["valu_issue_frac"] = cs["SQ_INSTS_VALU"] * 4 / (1024 * 2.4e9 * t)
+                rec["valu_issue_frac"] = cs["SQ_INSTS_VALU"] * 2 / (1024 * 2.4e9 * t)   # 2 cycles / wave64 instr
+                rec["cycles_per_valu_inst"] = 1024 * 2.4e9 * t / cs["SQ_INSTS_VALU"]
                 rec["hbm_traffic_GBps"] = rec["hbm_bytes_per_launch"] / t / 1e9
             print("\npmc record:", json.dumps(rec))
             with open(os.path.join(d, "pmc.json"), "w") as f:

@@ -115,6 +115,7 @@ SIGNATURES = {
     "gof_pipeline_profile_stride": (C.c_int, [C.c_void_p, C.c_int]),
     "gof_pipeline_profile_query": (C.c_int, [C.c_void_p, C.POINTER(C.c_double),
                                              C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "gof_pipeline_profile_span": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "gof_pipeline_profile_read": (C.c_int, [C.c_void_p, _f32p, _f32p, C.c_int, C.POINTER(C.c_int)]),
 }
 

@@ -1199,6 +1199,21 @@ int gof_pipeline_profile_query(gof_pipeline *p, double *detector_ms, double *mor
     return GOF_OK;
 }
 
+int gof_pipeline_profile_span(gof_pipeline *p, double *span_ms)
+{
+    if (!p || !span_ms)
+        return fail(GOF_EINVAL, "NULL argument");
+    *span_ms = 0.0;
+    if (p->prof_used == 0)
+        return GOF_OK;
+    GOF_HIP(hipSetDevice(p->ctx->device));
+    float ms = 0;
+    GOF_HIP(hipEventSynchronize(p->events[3 * (p->prof_used - 1) + 2]));
+    GOF_HIP(hipEventElapsedTime(&ms, p->events[0], p->events[3 * (p->prof_used - 1) + 2]));
+    *span_ms = ms;
+    return GOF_OK;
+}
+
 int gof_pipeline_profile_read(gof_pipeline *p, float *detector_ms, float *morph_ms, int capacity,
                               int *n_applies)
 {

@@ -153,6 +153,12 @@ class ForegroundPipeline:
                                                           C.byref(n)))
         return a.value, b.value, n.value
 
+    def profile_span(self):
+        """ms from the first bracketed step's first event to the last one's last event"""
+        v = C.c_double()
+        _lib.check(_lib.load().gof_pipeline_profile_span(self._h, C.byref(v)))
+        return v.value
+
     def profile_read(self, capacity):
         """-> (detector-kernel ms, morphology-kernel ms) arrays, one entry per measured step"""
         a, b, n = np.zeros(capacity, np.float32), np.zeros(capacity, np.float32), C.c_int()

@@ -162,7 +162,8 @@ def test_fd_golden():
 # ---- step 2a: MOG2 ---------------------------------------------------------
 
 def _assert_state_equal(got, want):
-    live = np.arange(5)[:, None] < want["modes"][None, :]
+    assert got["weight"].shape == want["weight"].shape   # (nmixtures, n) on both sides
+    live = np.arange(want["weight"].shape[0])[:, None] < want["modes"][None, :]
     assert np.array_equal(got["modes"], want["modes"])
     assert np.array_equal(got["weight"][live], want["weight"][live])
     assert np.array_equal(got["var"][live], want["var"][live])
@@ -408,10 +409,6 @@ def test_multi_frame_kernel_other_rates(oracle, over):
             want = oracle.dilate(oracle.erode(ref.apply(oracle.gaussian_blur(frames[i])), k5), k5)
             assert np.array_equal(got[i], want), (over, 8 * r + i)
     want = ref.export()
-    K = want["weight"].shape[0]       # the oracle exports nmixtures slots, the library always 5
-    pad = lambda a: np.concatenate([a, np.zeros((5 - K,) + a.shape[1:], a.dtype)])
-    want = {"modes": want["modes"], "weight": pad(want["weight"]), "var": pad(want["var"]),
-            "mean": pad(want["mean"])}
     _assert_state_equal(gpu.mog2_state(), want)
 
 
