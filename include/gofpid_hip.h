@@ -221,6 +221,52 @@ int gof_find_external_contours(const uint8_t *mask, int h, int w, int32_t **poin
                                int32_t **offsets, int *n_contours);
 void gof_free(void *p);
 
+/* ---- step 4 front end on the GPU: external contours + blob statistics ----------
+ * Replaces helpers.find_contours(mask) = cv.findContours(mask, RETR_EXTERNAL,
+ * CHAIN_APPROX_NONE) [helpers.py:125-150], the filter cv.contourArea(contour) >=
+ * area_min [pipeline.py:555-572] and the cv.moments / np.max evaluations of
+ * get_bottom / get_center [helpers.py:153-168]: only the records and the contour
+ * points of blobs that pass the filter leave the device (KBs, not the 2 MB mask).
+ * Results equal gof_find_external_contours + the same filter: same contours, same
+ * order, same points.  a00/a10/a01 are the exact integer shoelace sums of the contour
+ * polygon: cv.contourArea = |a00| / 2; cv.moments: s = a00 < 0 ? -1 : 1, m00 = s a00 / 2,
+ * m10 = s a10 / 6, m01 = s a01 / 6; cv.boundingRect = (xmin, ymin, xmax - xmin + 1,
+ * ymax - ymin + 1). */
+typedef struct gof_blobs gof_blobs;
+typedef struct gof_blob_record {
+    int32_t x0, y0;                     /* first contour point (raster-first pixel) */
+    int32_t xmin, ymin, xmax, ymax;
+    int32_t n_points, point_offset;     /* its points: points_xy[2*point_offset ...] */
+    int64_t a00, a10, a01;
+} gof_blob_record;
+enum {                                  /* gof_blobs_counts flags: the image's result is not */
+    GOF_BLOBS_CRACK_OVERFLOW = 1,       /* available (mask too intricate for the scratch);    */
+    GOF_BLOBS_BLOB_OVERFLOW = 2,        /* the caller falls back to the mask itself            */
+    GOF_BLOBS_POINT_OVERFLOW = 4
+};
+/* scratch for n_images masks of (h, w); crack_capacity = border-edge slots per image
+ * (0: h*w/2, enough for any mask a morphological open/close leaves) */
+int gof_blobs_create(gof_ctx *ctx, int n_images, int h, int w, int crack_capacity, gof_blobs **out);
+void gof_blobs_destroy(gof_blobs *b);
+/* Enqueue the extraction for n_images masks (device, back to back) with
+ * cv.contourArea >= min_area, and the copy of the result heads to the host. */
+int gof_blobs_extract_dev(gof_blobs *b, const void *d_masks, int n_images, double min_area,
+                          void *stream);
+/* The same from host masks (n_images x (h, w) uint8, uploaded first); synchronous. */
+int gof_blobs_extract_host(gof_blobs *b, const uint8_t *masks, int n_images, double min_area);
+/* Wait for the last extraction; counts and flags of one image. */
+int gof_blobs_counts(gof_blobs *b, int image, int *n_blobs, int *n_points, int *flags);
+/* Records (n_blobs of them) and contour points ((x, y) int32 pairs, n_points of them,
+ * contour k = points [point_offset, point_offset + n_points) of record k). */
+int gof_blobs_fetch(gof_blobs *b, int image, gof_blob_record *records, int max_records,
+                    int32_t *points_xy, int max_points);
+/* steps 1-3 for n_frames frames of every stream from host buffers + the extraction on
+ * the resulting masks, which stay on the device (gof_pipeline_fetch_masks downloads them):
+ * image index = frame * streams + stream.  b must hold n_frames * streams images. */
+int gof_pipeline_apply_host_blobs(gof_pipeline *p, const uint8_t *frames, int n_frames,
+                                  gof_blobs *b, double min_area);
+int gof_pipeline_fetch_masks(gof_pipeline *p, uint8_t *masks, int n_frames);
+
 /* Per-kernel timing with HIP events on the launch stream (what bench.py's
  * roofline block is computed from).  enable != 0: every following apply
  * brackets its detector kernel (fused blur + MOG2, or FD) and its morphology

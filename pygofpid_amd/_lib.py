@@ -39,6 +39,13 @@ class MorphOp(C.Structure):
     _fields_ = [("op", C.c_int), ("kh", C.c_int), ("kw", C.c_int), ("kernel", _u8p)]
 
 
+class BlobRecord(C.Structure):
+    _fields_ = [("x0", C.c_int32), ("y0", C.c_int32), ("xmin", C.c_int32), ("ymin", C.c_int32),
+                ("xmax", C.c_int32), ("ymax", C.c_int32), ("n_points", C.c_int32),
+                ("point_offset", C.c_int32), ("a00", C.c_int64), ("a10", C.c_int64),
+                ("a01", C.c_int64)]
+
+
 class PipelineDesc(C.Structure):
     _fields_ = [
         ("streams", C.c_int), ("h", C.c_int), ("w", C.c_int), ("c", C.c_int),
@@ -111,6 +118,16 @@ SIGNATURES = {
                                              C.POINTER(C.POINTER(C.c_int32)),
                                              C.POINTER(C.c_int)]),
     "gof_free": (None, [C.c_void_p]),
+    "gof_blobs_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.POINTER(C.c_void_p)]),
+    "gof_blobs_destroy": (None, [C.c_void_p]),
+    "gof_blobs_extract_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p]),
+    "gof_blobs_extract_host": (C.c_int, [C.c_void_p, _u8p, C.c_int, C.c_double]),
+    "gof_blobs_counts": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                   C.POINTER(C.c_int)]),
+    "gof_blobs_fetch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
+    "gof_pipeline_apply_host_blobs": (C.c_int, [C.c_void_p, _u8p, C.c_int, C.c_void_p, C.c_double]),
+    "gof_pipeline_fetch_masks": (C.c_int, [C.c_void_p, _u8p, C.c_int]),
     "gof_pipeline_profile_enable": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "gof_pipeline_profile_stride": (C.c_int, [C.c_void_p, C.c_int]),
     "gof_pipeline_profile_query": (C.c_int, [C.c_void_p, C.POINTER(C.c_double),

@@ -1,0 +1,119 @@
+"""Step 4's front end on the GPU: external contours and blob statistics of the final
+foreground mask (gof_blobs in the C ABI, kernels in csrc/gof_blobs.hip).
+
+Replaces, for masks that are already on the device, the reference's
+`helpers.find_contours(mask)` (cv.findContours RETR_EXTERNAL / CHAIN_APPROX_NONE,
+pygofpid/helpers.py:125-150), the `cv.contourArea(contour) >= area_min` filter of
+`GOFPID._find_blob` (pipeline.py:555-572) and the `cv.moments` / `np.max` evaluations of
+`get_bottom` / `get_center` (helpers.py:153-168).  Same contours, same order, same points
+as the host path (`hostcv.findContours` + the same filter), which stays the checker and
+the fall-back for masks too intricate for the device scratch.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+RECORD_DTYPE = np.dtype([("x0", "<i4"), ("y0", "<i4"), ("xmin", "<i4"), ("ymin", "<i4"),
+                         ("xmax", "<i4"), ("ymax", "<i4"), ("n_points", "<i4"),
+                         ("point_offset", "<i4"), ("a00", "<i8"), ("a10", "<i8"), ("a01", "<i8")])
+assert RECORD_DTYPE.itemsize == C.sizeof(_lib.BlobRecord)
+
+
+class BlobExtractor:
+    """Scratch + result buffers for `n_images` masks of (h, w) on one device."""
+
+    def __init__(self, n_images, h, w, ctx=None, device=None, crack_capacity=0):
+        self.n_images, self.h, self.w = int(n_images), int(h), int(w)
+        self._ctx = ctx if ctx is not None else _lib.default_context(device)
+        self._h = C.c_void_p()
+        _lib.check(_lib.load().gof_blobs_create(self._ctx.handle, self.n_images, self.h, self.w,
+                                                int(crack_capacity), C.byref(self._h)))
+
+    @property
+    def handle(self):
+        return self._h
+
+    def extract_device(self, masks_ptr, n_images=None, min_area=100.0, stream=None):
+        """Enqueue the extraction on device masks (an int pointer); does not synchronise."""
+        _lib.check(_lib.load().gof_blobs_extract_dev(
+            self._h, C.c_void_p(masks_ptr), int(n_images or self.n_images), float(min_area),
+            C.c_void_p(stream) if stream else None))
+
+    def extract(self, masks, min_area=100.0):
+        """Host masks (h, w) or (n, h, w) uint8 -> list of results (see result())."""
+        m = _lib.as_u8(masks, "masks")
+        if m.ndim == 2:
+            m = m[None]
+        if m.ndim != 3 or m.shape[1:] != (self.h, self.w) or m.shape[0] > self.n_images:
+            raise ValueError("masks must be (n <= %d, %d, %d)" % (self.n_images, self.h, self.w))
+        _lib.check(_lib.load().gof_blobs_extract_host(self._h, _lib.p8(m), m.shape[0], float(min_area)))
+        return [self.result(i) for i in range(m.shape[0])]
+
+    def result(self, image):
+        """(records, points) of one image of the last extraction -- records: structured
+        array (RECORD_DTYPE) in cv2's contour order, points: (n_points, 2) int32 (x, y) --
+        or None when the device flagged an overflow (fall back to the mask)."""
+        nb, npts, fl = C.c_int(), C.c_int(), C.c_int()
+        lib = _lib.load()
+        _lib.check(lib.gof_blobs_counts(self._h, int(image), C.byref(nb), C.byref(npts), C.byref(fl)))
+        if fl.value:
+            return None
+        recs = np.zeros(nb.value, RECORD_DTYPE)
+        pts = np.zeros((npts.value, 2), np.int32)
+        _lib.check(lib.gof_blobs_fetch(self._h, int(image), recs.ctypes.data_as(C.c_void_p), nb.value,
+                                       pts.ctypes.data_as(C.c_void_p), npts.value))
+        return recs, pts
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.load().gof_blobs_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def contours_of(records, points):
+    """The contours as cv2 returns them: a list of (n, 1, 2) int32 arrays."""
+    return [points[r["point_offset"]:r["point_offset"] + r["n_points"]].reshape(-1, 1, 2)
+            for r in records]
+
+
+def moments_of(rec):
+    """cv.moments(contour) entries m00, m10, m01 from the exact shoelace sums
+    (same expressions as hostcv.moments)."""
+    s = -1.0 if rec["a00"] < 0 else 1.0
+    return {"m00": s * float(rec["a00"]) / 2.0, "m10": s * float(rec["a10"]) / 6.0,
+            "m01": s * float(rec["a01"]) / 6.0}
+
+
+def bottom_and_center(rec, dtype=np.int16):
+    """helpers.get_bottom / get_center of the record's contour [REF helpers.py:153-168]."""
+    m = moments_of(rec)
+    x = int(m["m10"] / m["m00"])
+    return (np.array([x, int(rec["ymax"])], dtype=dtype),
+            np.array([x, int(m["m01"] / m["m00"])], dtype=dtype))
+
+
+def host_result(mask, min_area=100.0):
+    """The same (records, points) from the host contour follower: the checker of the
+    device path, and its fall-back."""
+    from . import hostcv
+    recs, pts, off = [], [], 0
+    for c in hostcv.findContours(mask):
+        if hostcv.contourArea(c) < min_area:
+            continue
+        p = c.reshape(-1, 2).astype(np.int64)
+        x0, y0 = np.roll(p[:, 0], 1), np.roll(p[:, 1], 1)
+        cr = x0 * p[:, 1] - p[:, 0] * y0
+        recs.append((p[0, 0], p[0, 1], p[:, 0].min(), p[:, 1].min(), p[:, 0].max(), p[:, 1].max(),
+                     len(p), off, cr.sum(), (cr * (x0 + p[:, 0])).sum(), (cr * (y0 + p[:, 1])).sum()))
+        pts.append(p.astype(np.int32))
+        off += len(p)
+    return (np.array(recs, RECORD_DTYPE) if recs else np.zeros(0, RECORD_DTYPE),
+            np.concatenate(pts) if pts else np.zeros((0, 2), np.int32))

@@ -137,6 +137,21 @@ struct gof_pipeline {
     size_t prof_seen = 0;      // applies since profiling was enabled
 };
 
+struct gof_blobs {
+    gof_ctx *ctx = nullptr;
+    int n_img = 0, h = 0, w = 0;
+    gofk::BlobBuffers B{};
+    void *dev = nullptr;            // one allocation behind every pointer of B
+    uint32_t *host = nullptr;       // pinned: [n_img][head_words], the head of every image's block
+    uint32_t head_words = 0;
+    std::vector<uint32_t> spill;    // an image's whole block when it exceeds the head
+    int spill_image = -1;
+    hipStream_t last = nullptr;
+    bool pending = false;
+    int n_last = 0;
+    DevBuf in;                      // masks of gof_blobs_extract_host
+};
+
 namespace {
 
 int make_taps(int kw, int kh, double sx, double sy, gofk::Taps *t)
@@ -885,6 +900,211 @@ int gof_morph_host(gof_ctx *ctx, int op, const uint8_t *src, uint8_t *dst, int h
     return GOF_OK;
 }
 
+/* ---- blob extraction ------------------------------------------------------- */
+
+int gof_blobs_create(gof_ctx *ctx, int n_images, int h, int w, int crack_capacity, gof_blobs **out)
+{
+    if (!ctx || !out)
+        return fail(GOF_EINVAL, "NULL argument");
+    *out = nullptr;
+    int rc = check_geom(n_images, h, w, 1);
+    if (rc)
+        return rc;
+    if (h > 65535 || w > 65535 || n_images > 65535 || (size_t)h * w > ((size_t)1 << 30) || crack_capacity < 0)
+        return fail(GOF_EINVAL, "blob extraction takes masks up to 65535 x 65535 (2^30 pixels)");
+    const size_t N = (size_t)h * w;
+    size_t cap = crack_capacity ? (size_t)crack_capacity : N / 2;
+    if (cap < 4096)
+        cap = 4096;
+    if (cap > 2 * N + 16)
+        cap = 2 * N + 16;           // no mask has more border edges than that
+    cap = (cap + 3) & ~(size_t)3;
+    if (cap > ((size_t)1 << 28))
+        return fail(GOF_EINVAL, "crack capacity too large");
+    gof_blobs *b = new (std::nothrow) gof_blobs;
+    if (!b)
+        return fail(GOF_ENOMEM, "host allocation failed");
+    b->ctx = ctx;
+    b->n_img = n_images;
+    b->h = h;
+    b->w = w;
+    gofk::BlobBuffers &B = b->B;
+    B.n_img = n_images;
+    B.h = h;
+    B.w = w;
+    B.cap = (uint32_t)cap;
+    // header + up to 1024 records + one point per four crack slots
+    B.out_words = gofk::kBlobHeaderWords + 1024 * gofk::kBlobRecordWords + (uint32_t)(cap / 4);
+    const size_t n = (size_t)n_images;
+    const size_t acc_words = n * (cap / 4) * sizeof(gofk::BlobAcc) / 4;
+    const size_t words = acc_words + n * N + 11 * n * cap + n * gofk::kBlobCounters + n * B.out_words;
+    const size_t bytes = words * 4 + 256;
+    GOF_HIP(hipSetDevice(ctx->device));
+    hipError_t e = hipMalloc(&b->dev, bytes);
+    if (e != hipSuccess) {
+        delete b;
+        return fail(GOF_ENOMEM, "hipMalloc(%zu B of blob scratch): %s", bytes, hipGetErrorString(e));
+    }
+    uint32_t *q = (uint32_t *)b->dev;
+    auto take = [&](size_t cnt) {
+        uint32_t *r = q;
+        q += cnt;
+        return r;
+    };
+    B.acc = (gofk::BlobAcc *)take(acc_words);   // 8-byte aligned: first
+    B.cbase = take(n * N);
+    B.ckey = take(n * cap);
+    B.csucc = take(n * cap);
+    B.cparent = take(n * cap);
+    B.caux = take(n * cap);
+    B.cpos = take(n * cap);
+    B.rsel = take(n * cap);
+    B.rnxt = take(n * cap);
+    B.rsum = take(n * cap);
+    B.rnxt2 = take(n * cap);
+    B.rsum2 = take(n * cap);
+    B.counters = take(n * gofk::kBlobCounters);
+    B.out = take(n * B.out_words);
+    b->head_words = B.out_words < 8192u ? B.out_words : 8192u;   // 32 KB per image travel unasked
+    e = hipHostMalloc((void **)&b->host, n * b->head_words * 4, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        (void)hipFree(b->dev);
+        delete b;
+        return fail(GOF_ENOMEM, "hipHostMalloc: %s", hipGetErrorString(e));
+    }
+    *out = b;
+    return GOF_OK;
+}
+
+void gof_blobs_destroy(gof_blobs *b)
+{
+    if (!b)
+        return;
+    (void)hipSetDevice(b->ctx->device);
+    if (b->last)
+        (void)hipStreamSynchronize(b->last);
+    (void)hipStreamSynchronize(b->ctx->stream);
+    if (b->dev)
+        (void)hipFree(b->dev);
+    if (b->host)
+        (void)hipHostFree(b->host);
+    b->in.release();
+    delete b;
+}
+
+int gof_blobs_extract_dev(gof_blobs *b, const void *d_masks, int n_images, double min_area, void *stream)
+{
+    if (!b || !d_masks)
+        return fail(GOF_EINVAL, "NULL argument");
+    if (n_images < 1 || n_images > b->n_img)
+        return fail(GOF_EINVAL, "n_images must be in [1, %d], got %d", b->n_img, n_images);
+    if (!(min_area == min_area))
+        return fail(GOF_EINVAL, "min_area is NaN");
+    GOF_HIP(hipSetDevice(b->ctx->device));
+    hipStream_t s = pick(b->ctx, stream);
+    gofk::BlobBuffers B = b->B;
+    B.n_img = n_images;
+    GOF_HIP(gofk::blob_extract((const uint8_t *)d_masks, B, min_area, s));
+    GOF_HIP(hipMemcpy2DAsync(b->host, (size_t)b->head_words * 4, B.out, (size_t)B.out_words * 4,
+                             (size_t)b->head_words * 4, (size_t)n_images, hipMemcpyDeviceToHost, s));
+    b->last = s;
+    b->pending = true;
+    b->n_last = n_images;
+    b->spill_image = -1;
+    return GOF_OK;
+}
+
+int gof_blobs_extract_host(gof_blobs *b, const uint8_t *masks, int n_images, double min_area)
+{
+    if (!b || !masks)
+        return fail(GOF_EINVAL, "NULL argument");
+    if (n_images < 1 || n_images > b->n_img)
+        return fail(GOF_EINVAL, "n_images must be in [1, %d], got %d", b->n_img, n_images);
+    GOF_HIP(hipSetDevice(b->ctx->device));
+    const size_t bytes = (size_t)n_images * b->h * b->w;
+    int rc;
+    if ((rc = b->in.reserve(bytes)))
+        return rc;
+    hipStream_t s = b->ctx->stream;
+    GOF_HIP(hipMemcpyAsync(b->in.p, masks, bytes, hipMemcpyHostToDevice, s));
+    if ((rc = gof_blobs_extract_dev(b, b->in.p, n_images, min_area, nullptr)))
+        return rc;
+    GOF_HIP(hipStreamSynchronize(s));
+    b->pending = false;
+    return GOF_OK;
+}
+
+namespace {
+int blobs_wait(gof_blobs *b, int image)
+{
+    if (!b)
+        return fail(GOF_EINVAL, "NULL argument");
+    if (image < 0 || image >= b->n_last)
+        return fail(GOF_EINVAL, "image %d out of range [0, %d)", image, b->n_last);
+    if (b->pending) {
+        GOF_HIP(hipSetDevice(b->ctx->device));
+        GOF_HIP(hipStreamSynchronize(b->last));
+        b->pending = false;
+    }
+    return GOF_OK;
+}
+}  // namespace
+
+int gof_blobs_counts(gof_blobs *b, int image, int *n_blobs, int *n_points, int *flags)
+{
+    if (!n_blobs || !n_points || !flags)
+        return fail(GOF_EINVAL, "NULL argument");
+    int rc = blobs_wait(b, image);
+    if (rc)
+        return rc;
+    const gofk::BlobHeader *h = (const gofk::BlobHeader *)(b->host + (size_t)image * b->head_words);
+    *n_blobs = (int)h->n_blobs;
+    *n_points = (int)h->n_points;
+    *flags = (int)h->flags;
+    return GOF_OK;
+}
+
+int gof_blobs_fetch(gof_blobs *b, int image, gof_blob_record *records, int max_records,
+                    int32_t *points_xy, int max_points)
+{
+    int rc = blobs_wait(b, image);
+    if (rc)
+        return rc;
+    const uint32_t *blk = b->host + (size_t)image * b->head_words;
+    const gofk::BlobHeader h = *(const gofk::BlobHeader *)blk;
+    if (h.flags != 0)
+        return fail(GOF_EINVAL, "image %d has no result (flags %u): fall back to the mask", image, h.flags);
+    if ((int)h.n_blobs > max_records || (int)h.n_points > max_points || (h.n_blobs && !records) ||
+        (h.n_points && !points_xy))
+        return fail(GOF_EINVAL, "image %d holds %u blobs / %u points, buffers take %d / %d", image,
+                    h.n_blobs, h.n_points, max_records, max_points);
+    const size_t words = gofk::kBlobHeaderWords + (size_t)h.n_blobs * gofk::kBlobRecordWords + h.n_points;
+    if (words > b->head_words) {   // the rest of a large result, on demand
+        if (b->spill_image != image) {
+            try {
+                b->spill.resize(words);
+            } catch (const std::bad_alloc &) {
+                return fail(GOF_ENOMEM, "host allocation failed");
+            }
+            GOF_HIP(hipSetDevice(b->ctx->device));
+            GOF_HIP(hipMemcpyAsync(b->spill.data(), b->B.out + (size_t)image * b->B.out_words, words * 4,
+                                   hipMemcpyDeviceToHost, b->last));
+            GOF_HIP(hipStreamSynchronize(b->last));
+            b->spill_image = image;
+        }
+        blk = b->spill.data();
+    }
+    static_assert(sizeof(gof_blob_record) == sizeof(gofk::BlobRecord), "record layouts differ");
+    if (h.n_blobs)
+        memcpy(records, blk + gofk::kBlobHeaderWords, (size_t)h.n_blobs * sizeof(gof_blob_record));
+    const uint32_t *pts = blk + gofk::kBlobHeaderWords + (size_t)h.n_blobs * gofk::kBlobRecordWords;
+    for (uint32_t i = 0; i < h.n_points; i++) {
+        points_xy[2 * i] = (int32_t)(pts[i] & 0xffffu);
+        points_xy[2 * i + 1] = (int32_t)(pts[i] >> 16);
+    }
+    return GOF_OK;
+}
+
 /* ---- fused pipeline ------------------------------------------------------ */
 
 int gof_pipeline_create(gof_ctx *ctx, const gof_pipeline_desc *desc, gof_pipeline **out)
@@ -1151,6 +1371,46 @@ int gof_pipeline_apply_host_many(gof_pipeline *p, const uint8_t *frames, uint8_t
 int gof_pipeline_apply_host(gof_pipeline *p, const uint8_t *frames, uint8_t *masks)
 {
     return gof_pipeline_apply_host_many(p, frames, masks, 1);
+}
+
+int gof_pipeline_apply_host_blobs(gof_pipeline *p, const uint8_t *frames, int n_frames, gof_blobs *b,
+                                  double min_area)
+{
+    if (!p || !frames || !b)
+        return fail(GOF_EINVAL, "NULL argument");
+    if (n_frames < 1 || n_frames > 4096)
+        return fail(GOF_EINVAL, "n_frames must be in [1, 4096], got %d", n_frames);
+    if (b->ctx != p->ctx || b->h != p->d.h || b->w != p->d.w || b->n_img < n_frames * p->d.streams)
+        return fail(GOF_EINVAL, "blob scratch (%d images of %dx%d) does not fit %d frames of %d streams of %dx%d",
+                    b->n_img, b->h, b->w, n_frames, p->d.streams, p->d.h, p->d.w);
+    GOF_HIP(hipSetDevice(p->ctx->device));
+    hipStream_t s = p->ctx->stream;
+    const size_t npx = (size_t)n_frames * p->d.streams * p->d.h * p->d.w;
+    int rc;
+    if ((rc = p->in.reserve(npx * p->d.c)) || (rc = p->out.reserve(npx)))
+        return rc;
+    GOF_HIP(hipMemcpyAsync(p->in.p, frames, npx * p->d.c, hipMemcpyHostToDevice, s));
+    if ((rc = gof_pipeline_apply_dev_many(p, p->in.p, p->out.p, n_frames, nullptr)))
+        return rc;
+    if ((rc = gof_blobs_extract_dev(b, p->out.p, n_frames * p->d.streams, min_area, nullptr)))
+        return rc;
+    GOF_HIP(hipStreamSynchronize(s));
+    b->pending = false;
+    return GOF_OK;
+}
+
+int gof_pipeline_fetch_masks(gof_pipeline *p, uint8_t *masks, int n_frames)
+{
+    if (!p || !masks || n_frames < 1)
+        return fail(GOF_EINVAL, "bad argument");
+    const size_t npx = (size_t)n_frames * p->d.streams * p->d.h * p->d.w;
+    if (!p->out.p || p->out.cap < npx)
+        return fail(GOF_EINVAL, "no masks of %d frame(s) on the device", n_frames);
+    GOF_HIP(hipSetDevice(p->ctx->device));
+    hipStream_t s = p->ctx->stream;
+    GOF_HIP(hipMemcpyAsync(masks, p->out.p, npx, hipMemcpyDeviceToHost, s));
+    GOF_HIP(hipStreamSynchronize(s));
+    return GOF_OK;
 }
 
 int gof_pipeline_profile_enable(gof_pipeline *p, int enable, int capacity)

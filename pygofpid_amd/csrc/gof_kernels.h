@@ -130,6 +130,49 @@ bool morph_rect_chain_supported(const RectChain &ch);
 hipError_t cvt_gray(const uint8_t *src, uint8_t *dst, int n_img, int h, int w, int c, bool rgb,
                     hipStream_t s);
 
+// ---- blob extraction (gof_blobs.hip) ----------------------------------------------------
+// One entry per border (crack cycle): exact shoelace sums of the border polygon, pixel
+// changes along it (= its number of contour points), bounding box.
+struct BlobAcc {
+    long long a00, a10, a01;   // sum cross, sum cross*(x0+x1), sum cross*(y0+y1) over the border's edges
+    int xmin, ymin, xmax, ymax;
+    int trans;                 // pixel changes around the cycle
+    uint32_t root;             // slot of the root crack (north crack of the raster-first pixel)
+    int out;                   // index of the blob record, -1 if the border is not returned
+    int pad_;
+};
+// Per-image output block, packed: header, n_blobs records, n_points points (x | y << 16).
+struct BlobHeader {
+    uint32_t n_blobs, n_points, flags, n_cracks;
+};
+struct BlobRecord {            // == gof_blob_record (include/gofpid_hip.h)
+    int x0, y0;                // start pixel: the border's first point
+    int xmin, ymin, xmax, ymax;
+    int n_points, point_offset;
+    long long a00, a10, a01;
+};
+constexpr uint32_t kBlobHeaderWords = sizeof(BlobHeader) / 4, kBlobRecordWords = sizeof(BlobRecord) / 4;
+constexpr int kBlobCounters = 4;
+enum { kCntCracks = 0, kCntRoots = 1, kCntFlags = 2 };
+enum { kFlagCrackOverflow = 1, kFlagBlobOverflow = 2, kFlagPointOverflow = 4 };
+
+struct BlobBuffers {           // device scratch for n_img masks of h x w; cap = crack slots per image
+    int n_img, h, w;
+    uint32_t cap;              // multiple of 4
+    uint32_t out_words;        // dwords of one image's output block
+    uint32_t *cbase;           // [n_img][h*w]  slot << 4 | side bits, for pixels that own cracks
+    uint32_t *ckey;            // [n_img][cap]  pixel * 4 + side
+    uint32_t *csucc, *cparent, *caux, *cpos;   // [n_img][cap] each
+    uint32_t *rsel, *rnxt, *rsum, *rnxt2, *rsum2;   // [n_img][cap] each: list-ranking scratch
+    BlobAcc *acc;              // [n_img][cap / 4]
+    uint32_t *counters;        // [n_img][kBlobCounters]
+    uint32_t *out;             // [n_img][out_words]
+};
+
+// External contours (RETR_EXTERNAL, CHAIN_APPROX_NONE) of n_img masks with polygon area
+// >= min_area: records + ordered points into B.out, one block per image.  Enqueues only.
+hipError_t blob_extract(const uint8_t *mask, const BlobBuffers &B, double min_area, hipStream_t s);
+
 // sum of modes[] (for m-bar); out is a device uint64 accumulator, zeroed by caller.
 hipError_t sum_modes(const uint8_t *modes, size_t n, unsigned long long *out, hipStream_t s);
 

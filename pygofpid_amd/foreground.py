@@ -105,6 +105,39 @@ class ForegroundPipeline:
         _lib.check(_lib.load().gof_pipeline_apply_host_many(self._h, _lib.p8(x), _lib.p8(out), T))
         return out[:, 0] if self.streams == 1 else out
 
+    # -- steps 1-3 + step 4's front end, masks stay on the device ---------------
+    def apply_blobs(self, frames, min_area=100.0):
+        """Steps 1-3 on `frames` (as apply() / apply_many(): (h,w[,c]), (streams,h,w[,c])
+        or (T,streams,h,w[,c])) followed by the GPU blob extraction on the resulting
+        masks [REF helpers.py:125-168, pipeline.py:555-572].  Only blob records and the
+        contour points of blobs with cv.contourArea >= min_area are downloaded; the
+        masks stay on the device until last_masks() asks for them.
+
+        Returns one (records, points) pair per mask, index = frame * streams + stream
+        (see blobs.BlobExtractor.result); an entry is None where the device scratch
+        overflowed -- the caller then uses the mask itself."""
+        from .blobs import BlobExtractor
+        x = _lib.as_u8(frames, "frames")
+        per = self.streams * self.h * self.w * self.c
+        if x.size % per:
+            raise ValueError("Input shape has changed.")
+        T = x.size // per
+        if getattr(self, "_blobs", None) is None or self._blobs.n_images < T * self.streams:
+            self._blobs = BlobExtractor(T * self.streams, self.h, self.w, ctx=self._ctx)
+        _lib.check(_lib.load().gof_pipeline_apply_host_blobs(self._h, _lib.p8(x), T, self._blobs.handle,
+                                                             float(min_area)))
+        self._last_T = T
+        return [self._blobs.result(i) for i in range(T * self.streams)]
+
+    def last_masks(self):
+        """The masks of the last apply_blobs() call, downloaded now: (T, streams, h, w)."""
+        T = getattr(self, "_last_T", 0)
+        if not T:
+            raise RuntimeError("no apply_blobs() call yet")
+        out = np.empty((T, self.streams, self.h, self.w), np.uint8)
+        _lib.check(_lib.load().gof_pipeline_fetch_masks(self._h, _lib.p8(out), T))
+        return out
+
     # -- device buffers (bench / serving loop) -------------------------------
     def apply_device(self, frames_ptr, masks_ptr, stream=None, n_frames=1):
         """Enqueue one step of n_frames frames per stream on device pointers (ints);

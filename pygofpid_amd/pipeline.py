@@ -13,7 +13,11 @@ What runs where
       download of the mask.  Any other callables are called exactly as the
       reference calls them (`fun(X, ksize, borderType)`, `.apply(X)`,
       `fun(mask, kernel)`).
-  steps 4-7 (blobs, tracking, post-filter, alarm; reference :478-491) on the
+  step 4's front end (contour retrieval, the area filter and the blob moments;
+      reference helpers.py:125-168, pipeline.py:555-572) on the GPU as well when
+      steps 1-3 are fused: only blob records and contour points are downloaded,
+      `foreground_mask_` is fetched from the device when it is read.
+  the rest of steps 4-7 (tracking, post-filter, alarm; reference :478-491) on the
       host, on `pygofpid_amd.hostcv` (no cv2 needed).
 
 Deliberate deviations, all off the hot path:
@@ -24,6 +28,7 @@ Deliberate deviations, all off the hot path:
 """
 import numpy as np
 
+from . import blobs as gpublobs
 from . import cv, hostcv
 from .foreground import ForegroundPipeline
 from .helpers import (SimpleLinearRegression, find_contours, get_bottom, get_bottom_and_center,
@@ -108,6 +113,9 @@ class GOFPID():
         self._alarm_system = {'already_in_alarm': False, 'duration': 0}
         self._fused = None          # ForegroundPipeline, built at the first frame
         self._fused_checked = False
+        self._mask = None           # host copy of the final mask (lazy on the fused path)
+        self._mask_on_device = False
+        self._gpu_blobs = None      # (records, points) of the last frame, or None
         return self
 
     def _check_polygon_param(self, key, default, check):
@@ -151,8 +159,8 @@ class GOFPID():
         if self.convert:
             X = cv.cvtColor(X, self.convert)
 
-        # steps 1-3 on the GPU
-        self.foreground_mask_ = self._foreground(X)
+        # steps 1-3 on the GPU (and, fused, the contours / blob statistics of step 4)
+        self._foreground(X)
 
         # steps 4-7 on the host
         self._find_blob()
@@ -189,6 +197,24 @@ class GOFPID():
                 return None
         return blur, self.frg_detect, morph
 
+    _AREA_MIN = 100   # the reference's fixed area_min (pipeline.py:555)
+
+    @property
+    def foreground_mask_(self):
+        """The final mask of the last frame.  On the fused path it lives on the device
+        and is downloaded when (and only when) it is read."""
+        if self._mask is None and self._mask_on_device:
+            self._mask = self._fused.last_masks()[0, 0]
+        if self._mask is None:
+            raise AttributeError("foreground_mask_")
+        return self._mask
+
+    @foreground_mask_.setter
+    def foreground_mask_(self, value):
+        self._mask = value
+        self._mask_on_device = False
+        self._gpu_blobs = None
+
     def _foreground(self, X):
         if not self._fused_checked:
             self._fused_checked = True
@@ -202,7 +228,11 @@ class GOFPID():
                 except ValueError:
                     self._fused = None      # e.g. kernel larger than the fused path takes
         if self._fused is not None:
-            return self._fused.apply(X)
+            # one upload, the kernels of steps 1-3, the blob extraction, one small download
+            self._gpu_blobs = self._fused.apply_blobs(X, min_area=self._AREA_MIN)[0]
+            self._mask = None
+            self._mask_on_device = True
+            return
         # generic path: the reference's own call sequence
         if self.blur:
             X = self.blur.get('fun')(X, self.blur.get('ksize'), self.blur.get('borderType'))
@@ -210,7 +240,7 @@ class GOFPID():
         if self.mat_morph:
             for d in self.mat_morph:
                 mask = d.get('fun')(mask, d.get('kernel'))
-        return mask
+        self.foreground_mask_ = mask
 
     # ----------------------------------------------------------- calibration
     def _calib_first_frame(self):
@@ -241,6 +271,16 @@ class GOFPID():
 
     # ----------------------------------------------------------------- blobs
     def _find_blob(self, area_min=100):
+        if self._gpu_blobs is not None and area_min == self._AREA_MIN:
+            # contours, area filter and moments came from the device with the mask's header
+            recs, pts = self._gpu_blobs
+            self.blobs_ = []
+            for rec, contour in zip(recs, gpublobs.contours_of(recs, pts)):
+                bottom, center = gpublobs.bottom_and_center(rec, dtype=np.int16)
+                anchor = bottom if self.post_filter['anchor'] == 'bottom' else center
+                self.blobs_.append({'contour': contour, 'anchor': anchor, 'bottom': bottom,
+                                    'center': center})
+            return
         contours = [c for c in find_contours(self.foreground_mask_)
                     if hostcv.contourArea(c) >= area_min]
         self.blobs_ = [self._create_blob(c) for c in contours]
