@@ -242,7 +242,8 @@ typedef struct gof_blob_record {
 enum {                                  /* gof_blobs_counts flags: the image's result is not */
     GOF_BLOBS_CRACK_OVERFLOW = 1,       /* available (mask too intricate for the scratch);    */
     GOF_BLOBS_BLOB_OVERFLOW = 2,        /* the caller falls back to the mask itself            */
-    GOF_BLOBS_POINT_OVERFLOW = 4
+    GOF_BLOBS_POINT_OVERFLOW = 4,
+    GOF_BLOBS_INTERNAL = 8              /* a device-side loop bound was hit (a bug: report it) */
 };
 /* scratch for n_images masks of (h, w); crack_capacity = border-edge slots per image
  * (0: h*w/2, enough for any mask a morphological open/close leaves) */

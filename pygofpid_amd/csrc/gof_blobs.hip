@@ -39,39 +39,51 @@ namespace {
 constexpr unsigned SN = 0, SW = 1, SS = 2, SE = 3;
 constexpr uint32_t NIL = 0xffffffffu;
 
-__device__ __forceinline__ uint32_t ld_coherent(const uint32_t *p)
+// Parent pointers are read and rewritten by workgroups on different XCDs at the same
+// time.  The per-XCD L2s are not coherent with each other and a compare-and-swap executes
+// at the memory side, so a plain (even sc1) load may keep returning an L2 copy that a
+// CAS elsewhere has long replaced -- a find would then present a stale root to its own CAS
+// for ever.  Every access to a parent pointer is therefore itself a memory-side atomic:
+// the read is a fetch-or of zero, the path-halving write a compare-and-swap.
+__device__ __forceinline__ uint32_t ld_parent(uint32_t *p)
 {
-    // parent pointers are rewritten by other workgroups (other XCDs) while this one reads
-    // them: agent-scope atomic load, never a value parked in this CU's L1
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __hip_atomic_fetch_or(p, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void st_coherent(uint32_t *p, uint32_t v)
+__device__ __forceinline__ bool cas_parent(uint32_t *p, uint32_t expect, uint32_t v)
 {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __hip_atomic_compare_exchange_strong(p, &expect, v, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // union-find over cracks, root = smallest key.  Keys strictly decrease along parent
 // pointers (a root is only ever linked under a root of smaller key; path halving
-// re-points to an ancestor), so concurrent finds / unions cannot form a loop.
-__device__ __forceinline__ uint32_t uf_find(uint32_t *parent, uint32_t i)
+// re-points to an ancestor), so concurrent finds / unions cannot form a loop.  Every
+// loop is bounded all the same: a bound that is hit raises kFlagInternal instead of
+// spinning (the host then falls back to the mask, and the tests fail).
+constexpr int kMaxFindSteps = 1 << 22, kMaxUnionTries = 1 << 16;
+
+__device__ __forceinline__ uint32_t uf_find(uint32_t *parent, uint32_t i, uint32_t *flags)
 {
-    for (;;) {
-        const uint32_t p = ld_coherent(parent + i);
+    for (int it = 0; it < kMaxFindSteps; it++) {
+        const uint32_t p = ld_parent(parent + i);
         if (p == i)
             return i;
-        const uint32_t g = ld_coherent(parent + p);
+        const uint32_t g = ld_parent(parent + p);
         if (g == p)
             return p;
-        st_coherent(parent + i, g);   // path halving
+        (void)cas_parent(parent + i, p, g);   // path halving (lost races change nothing)
         i = g;
     }
+    atomicOr(flags, (uint32_t)kFlagInternal);
+    return i;
 }
 
-__device__ __forceinline__ void uf_union(uint32_t *parent, const uint32_t *key, uint32_t a, uint32_t b)
+__device__ __forceinline__ void uf_union(uint32_t *parent, const uint32_t *key, uint32_t a, uint32_t b,
+                                         uint32_t *flags)
 {
-    for (;;) {
-        a = uf_find(parent, a);
-        b = uf_find(parent, b);
+    for (int it = 0; it < kMaxUnionTries; it++) {
+        a = uf_find(parent, a, flags);
+        b = uf_find(parent, b, flags);
         if (a == b)
             return;
         if (key[a] > key[b]) {
@@ -80,11 +92,10 @@ __device__ __forceinline__ void uf_union(uint32_t *parent, const uint32_t *key, 
             b = t;
         }
         // a has the smaller key: hang b under it, if b is still a root
-        uint32_t expect = b;
-        if (__hip_atomic_compare_exchange_strong(parent + b, &expect, a, __ATOMIC_RELAXED,
-                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        if (cas_parent(parent + b, b, a))
             return;
     }
+    atomicOr(flags, (uint32_t)kFlagInternal);
 }
 
 struct Nbr {   // 3 x 3 neighbourhood of a foreground pixel as booleans (outside = background)
@@ -182,7 +193,7 @@ __global__ __launch_bounds__(256) void blob_link_kernel(const uint8_t *__restric
     const int W = B.w, H = B.h;
     const size_t N = (size_t)W * H;
     const uint8_t *m = mask + (size_t)img * N;
-    const uint32_t *cnts = B.counters + (size_t)img * kBlobCounters;
+    uint32_t *cnts = B.counters + (size_t)img * kBlobCounters;
     if (cnts[kCntFlags] != 0)
         return;
     if (!(x < W && y < H) || m[(size_t)y * W + x] == 0)
@@ -213,7 +224,7 @@ __global__ __launch_bounds__(256) void blob_link_kernel(const uint8_t *__restric
         else
             cn = slot_of(e, nside);
         succ[ci] = cn;
-        uf_union(parent, key, ci, cn);
+        uf_union(parent, key, ci, cn, cnts + kCntFlags);
     };
     link(SW, b.sw, W - 1, SN, b.s, W, SS);
     link(SS, b.se, W + 1, SW, b.e, 1, SE);
@@ -232,8 +243,9 @@ __global__ __launch_bounds__(256) void blob_roots_kernel(BlobBuffers B)
     uint32_t *parent = B.cparent + (size_t)img * B.cap, *aux = B.caux + (size_t)img * B.cap;
     BlobAcc *acc = B.acc + (size_t)img * (B.cap / 4);
     for (uint32_t ci = blockIdx.x * 256 + threadIdx.x; ci < nc; ci += gridDim.x * 256) {
-        const uint32_t r = uf_find(parent, ci);
-        st_coherent(parent + ci, r);
+        const uint32_t r = uf_find(parent, ci, cnts + kCntFlags);
+        if (r != ci)   // memory-side like every other access to it; the last word on this pointer
+            (void)__hip_atomic_exchange(parent + ci, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (r == ci) {
             const uint32_t slot = atomicAdd(cnts + kCntRoots, 1u);   // <= cracks / 4 <= cap / 4
             aux[ci] = slot;
@@ -513,7 +525,8 @@ __global__ __launch_bounds__(FT) void blob_finish_kernel(const uint8_t *__restri
     __syncthreads();
     // pointer jumping, double-buffered: every step reads (sa, na) and writes (sb, nb)
     uint32_t *sa = rsum, *na = rnxt, *sb = B.rsum2 + (size_t)img * B.cap, *nb = B.rnxt2 + (size_t)img * B.cap;
-    for (;;) {
+    int go = 1;
+    for (int step = 0; step < 34 && go; step++) {   // 2^32 list elements at most
         int any = 0;
         for (uint32_t j = tid; j < nsel; j += FT) {
             const uint32_t n = na[j];
@@ -526,15 +539,18 @@ __global__ __launch_bounds__(FT) void blob_finish_kernel(const uint8_t *__restri
                 nb[j] = NIL;
             }
         }
-        const int go = __syncthreads_or(any);
+        go = __syncthreads_or(any);
         uint32_t *t = sa;
         sa = sb;
         sb = t;
         t = na;
         na = nb;
         nb = t;
-        if (!go)
-            break;
+    }
+    if (go) {   // a list without an end: cannot happen (every cycle holds its root crack)
+        if (tid == 0)
+            hdr->flags |= kFlagInternal;
+        return;
     }
 
     // F: every crack writes its pixel into its point's place (the cracks of one run write

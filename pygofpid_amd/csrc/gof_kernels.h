@@ -154,7 +154,7 @@ struct BlobRecord {            // == gof_blob_record (include/gofpid_hip.h)
 constexpr uint32_t kBlobHeaderWords = sizeof(BlobHeader) / 4, kBlobRecordWords = sizeof(BlobRecord) / 4;
 constexpr int kBlobCounters = 4;
 enum { kCntCracks = 0, kCntRoots = 1, kCntFlags = 2 };
-enum { kFlagCrackOverflow = 1, kFlagBlobOverflow = 2, kFlagPointOverflow = 4 };
+enum { kFlagCrackOverflow = 1, kFlagBlobOverflow = 2, kFlagPointOverflow = 4, kFlagInternal = 8 };
 
 struct BlobBuffers {           // device scratch for n_img masks of h x w; cap = crack slots per image
     int n_img, h, w;
