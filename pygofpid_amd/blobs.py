@@ -49,7 +49,12 @@ class BlobExtractor:
         if m.ndim != 3 or m.shape[1:] != (self.h, self.w) or m.shape[0] > self.n_images:
             raise ValueError("masks must be (n <= %d, %d, %d)" % (self.n_images, self.h, self.w))
         _lib.check(_lib.load().gof_blobs_extract_host(self._h, _lib.p8(m), m.shape[0], float(min_area)))
-        return [self.result(i) for i in range(m.shape[0])]
+        self.flags = []
+        out = []
+        for i in range(m.shape[0]):
+            out.append(self.result(i))
+            self.flags.append(self.last_flags)
+        return out
 
     def result(self, image):
         """(records, points) of one image of the last extraction -- records: structured
@@ -58,6 +63,7 @@ class BlobExtractor:
         nb, npts, fl = C.c_int(), C.c_int(), C.c_int()
         lib = _lib.load()
         _lib.check(lib.gof_blobs_counts(self._h, int(image), C.byref(nb), C.byref(npts), C.byref(fl)))
+        self.last_flags = fl.value
         if fl.value:
             return None
         recs = np.zeros(nb.value, RECORD_DTYPE)

@@ -933,8 +933,8 @@ int gof_blobs_create(gof_ctx *ctx, int n_images, int h, int w, int crack_capacit
     B.h = h;
     B.w = w;
     B.cap = (uint32_t)cap;
-    // header + up to 1024 records + one point per four crack slots
-    B.out_words = gofk::kBlobHeaderWords + 1024 * gofk::kBlobRecordWords + (uint32_t)(cap / 4);
+    // header + up to 4096 records + one point per four crack slots
+    B.out_words = gofk::kBlobHeaderWords + 4096 * gofk::kBlobRecordWords + (uint32_t)(cap / 4);
     const size_t n = (size_t)n_images;
     const size_t acc_words = n * (cap / 4) * sizeof(gofk::BlobAcc) / 4;
     const size_t words = acc_words + n * N + 11 * n * cap + n * gofk::kBlobCounters + n * B.out_words;

@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256) void blob_stats_kernel(BlobBuffers B)
 
 // ---- K5: select, order, rank, emit -- one 1024-thread workgroup per image -----------------------
 constexpr int FT = 1024;           // threads
-constexpr int kMaxCand = FT;       // outer borders that pass the area filter (one thread each in C)
+constexpr int kMaxBlobs = 4096;    // returned borders per image (more: kFlagBlobOverflow, the host takes the mask)
 
 __global__ __launch_bounds__(FT) void blob_finish_kernel(const uint8_t *__restrict__ mask, BlobBuffers B,
                                                          double min_area)
@@ -392,11 +392,11 @@ __global__ __launch_bounds__(FT) void blob_finish_kernel(const uint8_t *__restri
              *rnxt = B.rnxt + (size_t)img * B.cap, *rsum = B.rsum + (size_t)img * B.cap;
     BlobAcc *acc = B.acc + (size_t)img * (B.cap / 4);
 
-    __shared__ uint32_t cand[kMaxCand];       // accumulator slots
-    __shared__ uint32_t acc_slot[kMaxCand];   // accepted: slot, then (sorted) slot by rank
-    __shared__ uint32_t acc_key[kMaxCand];
+    __shared__ uint32_t acc_slot[kMaxBlobs];   // accepted borders: accumulator slot, by arrival
+    __shared__ uint32_t acc_key[kMaxBlobs];
+    __shared__ uint32_t by_rank[kMaxBlobs];    // accumulator slot by rank
     __shared__ uint32_t n_cand, n_acc, n_sel, flags;
-    __shared__ uint32_t pt_off[kMaxCand];
+    uint32_t *cand = rsel;                     // (the ranking scratch is free until phase D)
     if (tid == 0) {
         n_cand = n_acc = n_sel = 0;
         flags = 0;
@@ -407,16 +407,11 @@ __global__ __launch_bounds__(FT) void blob_finish_kernel(const uint8_t *__restri
     //    [REF pipeline.py:562-565: cv.contourArea(contour) >= area_min]
     for (uint32_t s = tid; s < nroots; s += FT) {
         const long long a00 = acc[s].a00;
-        if (a00 <= 0 && (double)(-a00) * 0.5 >= min_area) {
-            const uint32_t k = atomicAdd(&n_cand, 1u);
-            if (k < (uint32_t)kMaxCand)
-                cand[k] = s;
-            else
-                flags = kFlagBlobOverflow;
-        }
+        if (a00 <= 0 && (double)(-a00) * 0.5 >= min_area)
+            cand[atomicAdd(&n_cand, 1u)] = s;   // roots <= cap / 4
     }
     __syncthreads();
-    const uint32_t ncand = n_cand < (uint32_t)kMaxCand ? n_cand : (uint32_t)kMaxCand;
+    const uint32_t ncand = n_cand;
 
     // B: RETR_EXTERNAL = not inside another outer border.  Depth at the start pixel = outer
     //    borders entered minus outer borders left on the way there along its row.
@@ -441,34 +436,38 @@ __global__ __launch_bounds__(FT) void blob_finish_kernel(const uint8_t *__restri
         d = wave_sum32(d);
         if (lane == 0 && d == 0) {
             const uint32_t k = atomicAdd(&n_acc, 1u);
-            acc_slot[k] = slot;
-            acc_key[k] = rk;
+            if (k < (uint32_t)kMaxBlobs) {
+                acc_slot[k] = slot;
+                acc_key[k] = rk;
+            } else {
+                flags = kFlagBlobOverflow;
+            }
         }
     }
     __syncthreads();
-    const uint32_t nacc = n_acc;
+    const uint32_t nacc = n_acc < (uint32_t)kMaxBlobs ? n_acc : (uint32_t)kMaxBlobs;
 
     // C: cv2 returns the contours in discovery (raster) order of their start pixels = key order
-    uint32_t my_slot = 0, my_rank = 0;
-    if ((uint32_t)tid < nacc) {
-        my_slot = acc_slot[tid];
-        const uint32_t k = acc_key[tid];
+    for (uint32_t j = tid; j < nacc; j += FT) {
+        const uint32_t k = acc_key[j];
+        uint32_t rank = 0;
         for (uint32_t i = 0; i < nacc; i++)
-            my_rank += acc_key[i] < k ? 1u : 0u;
+            rank += acc_key[i] < k ? 1u : 0u;
+        by_rank[rank] = acc_slot[j];
     }
     __syncthreads();
-    if ((uint32_t)tid < nacc)
-        acc_slot[my_rank] = my_slot;
-    __syncthreads();
+    BlobRecord *recs = (BlobRecord *)(out + kBlobHeaderWords);
     if (tid == 0) {
         uint32_t off = 0;
+        const uint32_t words = kBlobHeaderWords + nacc * kBlobRecordWords;
+        const bool fits = words <= B.out_words && flags == 0;
         for (uint32_t r = 0; r < nacc; r++) {
-            pt_off[r] = off;
-            const int t = acc[acc_slot[r]].trans;
+            if (fits)
+                recs[r].point_offset = (int)off;
+            const int t = acc[by_rank[r]].trans;
             off += (uint32_t)(t > 0 ? t : 1);
         }
-        const uint32_t words = kBlobHeaderWords + nacc * kBlobRecordWords;
-        if (words > B.out_words || off > B.out_words - words)
+        if (!fits || off > B.out_words - words)
             flags |= kFlagPointOverflow;
         hdr->n_blobs = nacc;
         hdr->n_points = off;
@@ -476,27 +475,24 @@ __global__ __launch_bounds__(FT) void blob_finish_kernel(const uint8_t *__restri
         hdr->n_cracks = nc;
     }
     __syncthreads();
-    if (flags & kFlagPointOverflow)
+    if (flags != 0)
         return;   // (the host falls back to the mask itself)
-    BlobRecord *recs = (BlobRecord *)(out + kBlobHeaderWords);
     uint32_t *points = out + kBlobHeaderWords + nacc * kBlobRecordWords;
-    if ((uint32_t)tid < nacc) {
-        BlobAcc *a = acc + acc_slot[tid];
-        a->out = tid;
+    for (uint32_t r = tid; r < nacc; r += FT) {
+        BlobAcc *a = acc + by_rank[r];
+        a->out = (int)r;
         const uint32_t rk = key[a->root];
-        BlobRecord r;
-        r.x0 = (int)((rk >> 2) % (uint32_t)W);
-        r.y0 = (int)((rk >> 2) / (uint32_t)W);
-        r.xmin = a->xmin;
-        r.ymin = a->ymin;
-        r.xmax = a->xmax;
-        r.ymax = a->ymax;
-        r.n_points = a->trans > 0 ? a->trans : 1;
-        r.point_offset = (int)pt_off[tid];
-        r.a00 = a->a00;
-        r.a10 = a->a10;
-        r.a01 = a->a01;
-        recs[tid] = r;
+        BlobRecord *q = recs + r;   // (point_offset is in place)
+        q->x0 = (int)((rk >> 2) % (uint32_t)W);
+        q->y0 = (int)((rk >> 2) / (uint32_t)W);
+        q->xmin = a->xmin;
+        q->ymin = a->ymin;
+        q->xmax = a->xmax;
+        q->ymax = a->ymax;
+        q->n_points = a->trans > 0 ? a->trans : 1;
+        q->a00 = a->a00;
+        q->a10 = a->a10;
+        q->a01 = a->a01;
     }
     __syncthreads();
     if (nacc == 0)
@@ -563,7 +559,7 @@ __global__ __launch_bounds__(FT) void blob_finish_kernel(const uint8_t *__restri
         const int np = tot > 0 ? tot : 1;
         if (idx < np) {
             const uint32_t p = key[ci] >> 2;
-            points[pt_off[a->out] + (uint32_t)idx] = (p % (uint32_t)W) | ((p / (uint32_t)W) << 16);
+            points[(uint32_t)recs[a->out].point_offset + (uint32_t)idx] = (p % (uint32_t)W) | ((p / (uint32_t)W) << 16);
         }
     }
 }
