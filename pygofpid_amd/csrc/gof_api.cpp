@@ -937,7 +937,9 @@ int gof_blobs_create(gof_ctx *ctx, int n_images, int h, int w, int crack_capacit
     B.out_words = gofk::kBlobHeaderWords + 4096 * gofk::kBlobRecordWords + (uint32_t)(cap / 4);
     const size_t n = (size_t)n_images;
     const size_t acc_words = n * (cap / 4) * sizeof(gofk::BlobAcc) / 4;
-    const size_t words = acc_words + n * N + 11 * n * cap + n * gofk::kBlobCounters + n * B.out_words;
+    B.seg_cap = (uint32_t)h * (uint32_t)(4 * ((w + 255) / 256));
+    const size_t words = acc_words + n * N + 12 * n * cap + n * B.seg_cap + n * gofk::kBlobCounters +
+                         n * B.out_words;
     const size_t bytes = words * 4 + 256;
     GOF_HIP(hipSetDevice(ctx->device));
     hipError_t e = hipMalloc(&b->dev, bytes);
@@ -958,11 +960,13 @@ int gof_blobs_create(gof_ctx *ctx, int n_images, int h, int w, int crack_capacit
     B.cparent = take(n * cap);
     B.caux = take(n * cap);
     B.cpos = take(n * cap);
+    B.cslot = take(n * cap);
     B.rsel = take(n * cap);
     B.rnxt = take(n * cap);
     B.rsum = take(n * cap);
     B.rnxt2 = take(n * cap);
     B.rsum2 = take(n * cap);
+    B.segs = take(n * B.seg_cap);
     B.counters = take(n * gofk::kBlobCounters);
     B.out = take(n * B.out_words);
     b->head_words = B.out_words < 8192u ? B.out_words : 8192u;   // 32 KB per image travel unasked
@@ -1049,6 +1053,18 @@ int blobs_wait(gof_blobs *b, int image)
     return GOF_OK;
 }
 }  // namespace
+
+/* diagnostics (profiles/micro): the device counters of one image of the last extraction --
+ * tiles, cracks, roots, flags, then phase stamps of the finishing kernel; not in the header */
+extern "C" int gof_blobs_debug_counters(gof_blobs *b, int image, uint32_t *out16)
+{
+    int rc = blobs_wait(b, image);
+    if (rc || !out16)
+        return rc ? rc : GOF_EINVAL;
+    GOF_HIP(hipMemcpy(out16, b->B.counters + (size_t)image * gofk::kBlobCounters,
+                      gofk::kBlobCounters * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return GOF_OK;
+}
 
 int gof_blobs_counts(gof_blobs *b, int image, int *n_blobs, int *n_points, int *flags)
 {

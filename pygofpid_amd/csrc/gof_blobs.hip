@@ -123,55 +123,43 @@ __device__ __forceinline__ unsigned sides_of(const Nbr &b)
     return (b.n ? 0u : 1u << SN) | (b.w ? 0u : 1u << SW) | (b.s ? 0u : 1u << SS) | (b.e ? 0u : 1u << SE);
 }
 
-// ---- K1: find the cracks, give each a slot -------------------------------------------------
-// Tile 64 x 4, a wave per row, a pixel per lane; a wave whose 64 pixels are all zero leaves
-// at once (most of a surveillance mask).  Slots are handed out per wave with one atomic.
-__global__ __launch_bounds__(256) void blob_scan_kernel(const uint8_t *__restrict__ mask, BlobBuffers B)
+// ---- K0: which tiles hold any foreground ----------------------------------------------------
+// A surveillance mask is mostly zeros.  One pass at streaming rate (a dword per lane, a
+// wave per tile of 256 px x 16 rows, its 16 loads in flight together) lists the tiles that
+// are not; the per-pixel kernels below run on the list only.  Entry: ty << 16 | tx.
+constexpr int TX = 256, TY = 16;
+
+__global__ __launch_bounds__(256) void blob_flag_kernel(const uint8_t *__restrict__ mask, BlobBuffers B, int aligned)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int x = blockIdx.x * 64 + lane, y = blockIdx.y * 4 + wave, img = blockIdx.z;
+    const int ty = blockIdx.y * 4 + wave, img = blockIdx.z;
     const int W = B.w, H = B.h;
-    const size_t N = (size_t)W * H;
-    const uint8_t *m = mask + (size_t)img * N;
-    const bool in = x < W && y < H;
-    const bool fg = in && m[(size_t)y * W + x] != 0;
-    if (__builtin_amdgcn_ballot_w64(fg) == 0)
+    const int y0 = ty * TY;
+    if (y0 >= H)
         return;
-    unsigned sides = 0;
-    if (fg)
-        sides = sides_of(load_nbr(m, x, y, W, H));
-    const unsigned cnt = __builtin_popcount(sides);
-    const uint64_t b0 = __builtin_amdgcn_ballot_w64(cnt & 1u), b1 = __builtin_amdgcn_ballot_w64(cnt & 2u),
-                   b2 = __builtin_amdgcn_ballot_w64(cnt & 4u);
-    const unsigned total = __builtin_popcountll(b0) + 2 * __builtin_popcountll(b1) + 4 * __builtin_popcountll(b2);
-    if (total == 0)
-        return;
-    const uint64_t lt = ((uint64_t)1 << lane) - 1;
-    const unsigned pre = __builtin_popcountll(b0 & lt) + 2 * __builtin_popcountll(b1 & lt) +
-                         4 * __builtin_popcountll(b2 & lt);
-    uint32_t *cnts = B.counters + (size_t)img * kBlobCounters;
-    uint32_t base = 0;
-    if (lane == 0)
-        base = atomicAdd(cnts + kCntCracks, total);
-    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-    if (cnt == 0)
-        return;
-    const uint32_t ci = base + pre;
-    if (ci + cnt > B.cap) {
-        cnts[kCntFlags] = kFlagCrackOverflow;   // (same value from every writer)
-        return;
-    }
-    const uint32_t pix = (uint32_t)y * W + x;
-    B.cbase[(size_t)img * N + pix] = (ci << 4) | sides;
-    uint32_t *key = B.ckey + (size_t)img * B.cap, *parent = B.cparent + (size_t)img * B.cap;
-    unsigned r = 0;
+    const uint8_t *base = mask + (size_t)img * W * H;
+    const int x = blockIdx.x * TX + 4 * lane;
+    uint32_t any = 0;
 #pragma unroll
-    for (unsigned s = 0; s < 4; s++) {
-        if (sides & (1u << s)) {
-            key[ci + r] = pix * 4u + s;
-            parent[ci + r] = ci + r;
-            r++;
+    for (int r = 0; r < TY; r++) {
+        const int y = y0 + r < H ? y0 + r : H - 1;   // (rows past the end re-read the last one)
+        const uint8_t *row = base + (size_t)y * W;
+        if (aligned) {             // W % 4 == 0, 4-byte aligned base: whole dwords inside the row
+            if (x < W)
+                any |= *(const uint32_t *)(row + x);
+        } else {
+#pragma unroll
+            for (int b = 0; b < 4; b++)
+                if (x + b < W)
+                    any |= row[x + b];
         }
+    }
+    if (__builtin_amdgcn_ballot_w64(any != 0) == 0)
+        return;
+    if (lane == 0) {
+        uint32_t *cnts = B.counters + (size_t)img * kBlobCounters;
+        const uint32_t at = atomicAdd(cnts + kCntSegs, 1u);
+        B.segs[(size_t)img * B.seg_cap + at] = ((uint32_t)ty << 16) | blockIdx.x;   // <= seg_cap by construction
     }
 }
 
@@ -181,55 +169,279 @@ __device__ __forceinline__ uint32_t slot_of(uint32_t e, unsigned s)
     return (e >> 4) + __builtin_popcount((e & 15u) & ((1u << s) - 1u));
 }
 
-// ---- K2: successor of every crack, and union with it -----------------------------------------
-// Walking direction per side (background on the right): W south, S east, E north, N west.
-// At the far vertex: the diagonal pixel ahead-right, if foreground, takes over (turn right,
-// onto ITS previous side); else the pixel ahead (same side); else turn left (next side,
-// same pixel).
-__global__ __launch_bounds__(256) void blob_link_kernel(const uint8_t *__restrict__ mask, BlobBuffers B)
+// Successor rule.  Walking direction per side (background on the right): W south, S east,
+// E north, N west.  At the far vertex: the diagonal pixel ahead-right, if foreground, takes
+// over (turn right, onto ITS previous side); else the pixel ahead (same side); else turn
+// left (next side, same pixel).  Per side s of a pixel with neighbourhood b:
+//   dx, dy = offset of the successor's pixel, ns = the successor's side
+__device__ __forceinline__ void successor(const Nbr &b, unsigned s, int &dx, int &dy, unsigned &ns)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int x = blockIdx.x * 64 + lane, y = blockIdx.y * 4 + wave, img = blockIdx.z;
+    bool diag, ahead;
+    int ddx, ddy, adx, ady;
+    unsigned dside, nside;
+    switch (s) {
+    case SW: diag = b.sw; ddx = -1; ddy = 1; dside = SN; ahead = b.s; adx = 0; ady = 1; nside = SS; break;
+    case SS: diag = b.se; ddx = 1; ddy = 1; dside = SW; ahead = b.e; adx = 1; ady = 0; nside = SE; break;
+    case SE: diag = b.ne; ddx = 1; ddy = -1; dside = SS; ahead = b.n; adx = 0; ady = -1; nside = SN; break;
+    default: diag = b.nw; ddx = -1; ddy = -1; dside = SE; ahead = b.w; adx = -1; ady = 0; nside = SW; break;
+    }
+    if (diag) {
+        dx = ddx;
+        dy = ddy;
+        ns = dside;
+    } else if (ahead) {
+        dx = adx;
+        dy = ady;
+        ns = s;
+    } else {
+        dx = dy = 0;
+        ns = nside;
+    }
+}
+
+// ---- K1: per tile -- find the cracks, give each a slot, link and union inside the tile --------
+// One workgroup per listed tile.  The tile and a one-pixel frame sit in LDS; a thread owns
+// 16 consecutive pixels of a row, so slots follow raster order inside the tile and the
+// smallest local slot of a cycle part is its smallest key.  Links that stay inside the tile
+// are united in LDS (no global atomics); links that leave it are left to K2.
+constexpr int TBW = TX + 8;            // LDS row: 4 px to the left (one dword) .. 4 px to the right
+constexpr int kTileCracks = 2 * TX * TY;   // no tile has more border edges than two per pixel
+
+__device__ __forceinline__ uint32_t lds_find(uint32_t *lp, uint32_t i)
+{
+    for (;;) {
+        const uint32_t p = lp[i];
+        if (p == i)
+            return i;
+        const uint32_t g = lp[p];
+        if (g == p)
+            return p;
+        lp[i] = g;   // path halving; keys (= local slots) strictly decrease along parents
+        i = g;
+    }
+}
+
+__global__ __launch_bounds__(256) void blob_tile_kernel(const uint8_t *__restrict__ mask, BlobBuffers B, int aligned)
+{
+    __shared__ uint8_t tb[(TY + 2) * TBW];
+    __shared__ uint16_t lbase[TY * TX];        // first local slot of a pixel that owns cracks
+    __shared__ uint16_t lkey[kTileCracks];     // local slot -> local pixel << 2 | side
+    __shared__ uint32_t lparent[kTileCracks];
+    __shared__ uint32_t wsum[4];
+    __shared__ uint32_t gbase;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int img = blockIdx.y;
+    const int W = B.w, H = B.h;
+    const size_t N = (size_t)W * H;
+    const uint8_t *m = mask + (size_t)img * N;
+    uint32_t *cnts = B.counters + (size_t)img * kBlobCounters;
+    const uint32_t ntile = cnts[kCntSegs];
+    const uint32_t *wl = B.segs + (size_t)img * B.seg_cap;
+    uint32_t *cb = B.cbase + (size_t)img * N;
+    uint32_t *key = B.ckey + (size_t)img * B.cap, *parent = B.cparent + (size_t)img * B.cap,
+             *succ = B.csucc + (size_t)img * B.cap;
+    for (uint32_t t = blockIdx.x; t < ntile; t += gridDim.x) {
+        const uint32_t ent = wl[t];
+        const int x0 = (int)(ent & 0xffffu) * TX, y0 = (int)(ent >> 16) * TY;
+        __syncthreads();   // (LDS of the previous tile is no longer read)
+        // 1. tile + frame into LDS; outside the image = background
+        for (int i = tid; i < (TY + 2) * (TBW / 4); i += 256) {
+            const int r = i / (TBW / 4), d = i - r * (TBW / 4);
+            const int gy = y0 - 1 + r, gx = x0 - 4 + 4 * d;
+            uint32_t v = 0;
+            if (gy >= 0 && gy < H) {
+                const uint8_t *row = m + (size_t)gy * W;
+                if (aligned && gx >= 0 && gx + 4 <= W) {
+                    v = *(const uint32_t *)(row + gx);
+                } else {
+#pragma unroll
+                    for (int b = 0; b < 4; b++)
+                        if (gx + b >= 0 && gx + b < W)
+                            v |= (uint32_t)row[gx + b] << (8 * b);
+                }
+            }
+            *(uint32_t *)(tb + r * TBW + 4 * d) = v;
+        }
+        __syncthreads();
+        // 2. this thread's 16 pixels: side bits, crack count
+        const int r = tid >> 4, q = tid & 15;
+        const uint8_t *c = tb + (r + 1) * TBW + 4 + 16 * q;   // centre row, first pixel
+        uint64_t sides64 = 0;
+        unsigned cnt = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            if (c[k] != 0) {
+                const unsigned sd = (c[k - TBW] ? 0u : 1u << SN) | (c[k - 1] ? 0u : 1u << SW) |
+                                    (c[k + TBW] ? 0u : 1u << SS) | (c[k + 1] ? 0u : 1u << SE);
+                sides64 |= (uint64_t)sd << (4 * k);
+                cnt += __builtin_popcount(sd);
+            }
+        }
+        // 3. exclusive scan of cnt over the workgroup; one global atomic for the tile
+        unsigned inc = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned u = __shfl_up(inc, o, 64);
+            if (lane >= o)
+                inc += u;
+        }
+        if (lane == 63)
+            wsum[wave] = inc;
+        __syncthreads();
+        unsigned woff = 0, total = 0;
+#pragma unroll
+        for (int wv = 0; wv < 4; wv++) {
+            if (wv < wave)
+                woff += wsum[wv];
+            total += wsum[wv];
+        }
+        if (tid == 0)
+            gbase = total ? atomicAdd(cnts + kCntCracks, total) : 0u;
+        __syncthreads();
+        const uint32_t base = gbase;
+        if (total == 0)
+            continue;
+        if (base + total > B.cap) {
+            if (tid == 0)
+                cnts[kCntFlags] = kFlagCrackOverflow;
+            continue;
+        }
+        // 4. slots: local table for the links below, global table for K2 and the later kernels
+        uint32_t loff = woff + inc - cnt;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const unsigned sd = (unsigned)(sides64 >> (4 * k)) & 15u;
+            if (sd) {
+                const int lx = 16 * q + k;
+                lbase[r * TX + lx] = (uint16_t)loff;
+                const uint32_t pix = (uint32_t)(y0 + r) * W + (uint32_t)(x0 + lx);
+                cb[pix] = ((base + loff) << 4) | sd;
+#pragma unroll
+                for (unsigned sdx = 0; sdx < 4; sdx++) {
+                    if (sd & (1u << sdx)) {
+                        key[base + loff] = pix * 4u + sdx;
+                        lkey[loff] = (uint16_t)(((r * TX + lx) << 2) | sdx);
+                        lparent[loff] = loff;
+                        loff++;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // 5. links, one crack per thread and pass (a thread's own 16 pixels may all be border
+        //    pixels of a horizontal edge: the work is dealt out by slot instead); those that
+        //    stay inside the tile are united here
+        for (uint32_t li = tid; li < total; li += 256) {
+            const unsigned lk = lkey[li];
+            const unsigned sdx = lk & 3u;
+            const int lx = (int)((lk >> 2) & (TX - 1)), ly = (int)(lk >> 10);   // TX == 256
+            const uint8_t *p = tb + (ly + 1) * TBW + 4 + lx;
+            Nbr b;
+            b.n = p[-TBW] != 0;
+            b.s = p[TBW] != 0;
+            b.w = p[-1] != 0;
+            b.e = p[1] != 0;
+            b.nw = p[-TBW - 1] != 0;
+            b.ne = p[-TBW + 1] != 0;
+            b.sw = p[TBW - 1] != 0;
+            b.se = p[TBW + 1] != 0;
+            int dx, dy;
+            unsigned ns;
+            successor(b, sdx, dx, dy, ns);
+            const int nx = lx + dx, ny = ly + dy;
+            if (nx >= 0 && nx < TX && ny >= 0 && ny < TY) {
+                // the successor pixel's side bits, from its own 4-neighbourhood
+                const uint8_t *pn = p + dy * TBW + dx;
+                const unsigned nsd = (pn[-TBW] ? 0u : 1u << SN) | (pn[-1] ? 0u : 1u << SW) |
+                                     (pn[TBW] ? 0u : 1u << SS) | (pn[1] ? 0u : 1u << SE);
+                const uint32_t ln = (uint32_t)lbase[ny * TX + nx] + __builtin_popcount(nsd & ((1u << ns) - 1u));
+                succ[base + li] = base + ln;
+                // unite li and ln in LDS, root = smaller slot (= smaller key: slots follow raster order)
+                uint32_t a = li, bb = ln;
+                for (;;) {
+                    a = lds_find(lparent, a);
+                    bb = lds_find(lparent, bb);
+                    if (a == bb)
+                        break;
+                    if (a > bb) {
+                        const uint32_t tt = a;
+                        a = bb;
+                        bb = tt;
+                    }
+                    if (atomicCAS(lparent + bb, bb, a) == bb)
+                        break;
+                }
+            } else {
+                succ[base + li] = NIL;   // leaves the tile: K2
+            }
+        }
+        __syncthreads();
+        // 6. the tile's trees, flattened, as the global starting point
+        for (uint32_t li = tid; li < total; li += 256)
+            parent[base + li] = base + lds_find(lparent, li);
+    }
+}
+
+// ---- K2: the links that cross a tile border, united with memory-side atomics ---------------------
+// Per listed tile: the pixels of its first / last row and column (any pixel with a neighbour
+// in another tile); of their cracks, those whose successor lies outside the tile.
+__global__ __launch_bounds__(256) void blob_cross_kernel(const uint8_t *__restrict__ mask, BlobBuffers B)
+{
+    const int tid = threadIdx.x;
+    const int img = blockIdx.y;
     const int W = B.w, H = B.h;
     const size_t N = (size_t)W * H;
     const uint8_t *m = mask + (size_t)img * N;
     uint32_t *cnts = B.counters + (size_t)img * kBlobCounters;
     if (cnts[kCntFlags] != 0)
         return;
-    if (!(x < W && y < H) || m[(size_t)y * W + x] == 0)
-        return;
-    const Nbr b = load_nbr(m, x, y, W, H);
-    const unsigned sides = sides_of(b);
-    if (sides == 0)
-        return;
+    const uint32_t ntile = cnts[kCntSegs];
+    const uint32_t *wl = B.segs + (size_t)img * B.seg_cap;
     const uint32_t *cb = B.cbase + (size_t)img * N;
     const uint32_t *key = B.ckey + (size_t)img * B.cap;
     uint32_t *succ = B.csucc + (size_t)img * B.cap, *parent = B.cparent + (size_t)img * B.cap;
-    const uint32_t pix = (uint32_t)y * W + x;
-    const uint32_t e = cb[pix];
-    // per side: (ahead-right pixel is fg, its offset, its side) / (ahead pixel is fg, offset) / next side
-    //   W: walk S, right W -> ahead-right SW (side N), ahead S
-    //   S: walk E, right S -> ahead-right SE (side W), ahead E
-    //   E: walk N, right E -> ahead-right NE (side S), ahead N
-    //   N: walk W, right N -> ahead-right NW (side E), ahead W
-    auto link = [&](unsigned s, bool diag, int doff, unsigned dside, bool ahead, int aoff, unsigned nside) {
-        if (!(sides & (1u << s)))
-            return;
-        const uint32_t ci = slot_of(e, s);
-        uint32_t cn;
-        if (diag)
-            cn = slot_of(cb[(int)pix + doff], dside);
-        else if (ahead)
-            cn = slot_of(cb[(int)pix + aoff], s);
-        else
-            cn = slot_of(e, nside);
-        succ[ci] = cn;
-        uf_union(parent, key, ci, cn, cnts + kCntFlags);
-    };
-    link(SW, b.sw, W - 1, SN, b.s, W, SS);
-    link(SS, b.se, W + 1, SW, b.e, 1, SE);
-    link(SE, b.ne, -W + 1, SS, b.n, -W, SN);
-    link(SN, b.nw, -W - 1, SE, b.w, -1, SW);
+    for (uint32_t t = blockIdx.x; t < ntile; t += gridDim.x) {
+        const uint32_t ent = wl[t];
+        const int x0 = (int)(ent & 0xffffu) * TX, y0 = (int)(ent >> 16) * TY;
+        // border pixels: 256 of row 0, 256 of row 15, 14 + 14 of columns 0 and 255
+        for (int i = tid; i < 2 * TX + 2 * (TY - 2); i += 256) {
+            int lx, ly;
+            if (i < TX) {
+                lx = i;
+                ly = 0;
+            } else if (i < 2 * TX) {
+                lx = i - TX;
+                ly = TY - 1;
+            } else {
+                const int j = i - 2 * TX;
+                lx = j < TY - 2 ? 0 : TX - 1;
+                ly = 1 + (j < TY - 2 ? j : j - (TY - 2));
+            }
+            const int x = x0 + lx, y = y0 + ly;
+            if (x >= W || y >= H || m[(size_t)y * W + x] == 0)
+                continue;
+            const Nbr b = load_nbr(m, x, y, W, H);
+            const unsigned sd = sides_of(b);
+            if (!sd)
+                continue;
+            const uint32_t pix = (uint32_t)y * W + x;
+            const uint32_t e = cb[pix];
+            for (unsigned sdx = 0; sdx < 4; sdx++) {
+                if (!(sd & (1u << sdx)))
+                    continue;
+                int dx, dy;
+                unsigned ns;
+                successor(b, sdx, dx, dy, ns);
+                const int nx = lx + dx, ny = ly + dy;
+                if (nx >= 0 && nx < TX && ny >= 0 && ny < TY)
+                    continue;   // stayed inside: K1 did it
+                const uint32_t ci = slot_of(e, sdx);
+                const uint32_t cn = slot_of(cb[(int)pix + dy * W + dx], ns);
+                succ[ci] = cn;
+                uf_union(parent, key, ci, cn, cnts + kCntFlags);
+            }
+        }
+    }
 }
 
 // ---- K3: flatten; every root takes an accumulator slot ----------------------------------------
@@ -307,6 +519,7 @@ __global__ __launch_bounds__(256) void blob_stats_kernel(BlobBuffers B)
     const uint32_t nc = cnts[kCntCracks];
     const uint32_t *key = B.ckey + (size_t)img * B.cap, *succ = B.csucc + (size_t)img * B.cap,
                    *parent = B.cparent + (size_t)img * B.cap, *aux = B.caux + (size_t)img * B.cap;
+    uint32_t *cslot = B.cslot + (size_t)img * B.cap;
     BlobAcc *acc = B.acc + (size_t)img * (B.cap / 4);
     const uint32_t W = (uint32_t)B.w;
     const int lane = threadIdx.x & 63;
@@ -319,6 +532,7 @@ __global__ __launch_bounds__(256) void blob_stats_kernel(BlobBuffers B)
         int tr = 0, px = 0, py = 0;
         if (valid) {
             slot = aux[parent[ci]];
+            cslot[ci] = slot;   // (the finishing kernel goes from a crack to its border in one step)
             const uint32_t p0 = key[ci] >> 2, p1 = key[succ[ci]] >> 2;
             px = (int)(p0 % W);
             py = (int)(p0 / W);
@@ -387,14 +601,17 @@ __global__ __launch_bounds__(FT) void blob_finish_kernel(const uint8_t *__restri
     const uint32_t nc = cnts[kCntCracks], nroots = cnts[kCntRoots];
     const uint32_t *cb = B.cbase + (size_t)img * N;
     const uint32_t *key = B.ckey + (size_t)img * B.cap, *succ = B.csucc + (size_t)img * B.cap,
-                   *parent = B.cparent + (size_t)img * B.cap, *aux = B.caux + (size_t)img * B.cap;
+                   *parent = B.cparent + (size_t)img * B.cap;
+    const uint32_t *cslot = B.cslot + (size_t)img * B.cap;
     uint32_t *cpos = B.cpos + (size_t)img * B.cap, *rsel = B.rsel + (size_t)img * B.cap,
              *rnxt = B.rnxt + (size_t)img * B.cap, *rsum = B.rsum + (size_t)img * B.cap;
     BlobAcc *acc = B.acc + (size_t)img * (B.cap / 4);
 
-    __shared__ uint32_t acc_slot[kMaxBlobs];   // accepted borders: accumulator slot, by arrival
-    __shared__ uint32_t acc_key[kMaxBlobs];
-    __shared__ uint32_t by_rank[kMaxBlobs];    // accumulator slot by rank
+    // one LDS pool: phases A-C keep the accepted borders in it, phase E the ranking lists
+    __shared__ uint32_t pool[3 * kMaxBlobs];
+    uint32_t *acc_slot = pool;                   // accepted borders: accumulator slot, by arrival
+    uint32_t *acc_key = pool + kMaxBlobs;
+    uint32_t *by_rank = pool + 2 * kMaxBlobs;    // accumulator slot by rank
     __shared__ uint32_t n_cand, n_acc, n_sel, flags;
     uint32_t *cand = rsel;                     // (the ranking scratch is free until phase D)
     if (tid == 0) {
@@ -403,6 +620,8 @@ __global__ __launch_bounds__(FT) void blob_finish_kernel(const uint8_t *__restri
     }
     __syncthreads();
 
+    if (tid == 0)
+        cnts[4 + 0] = (uint32_t)wall_clock64();
     // A: outer borders (a00 <= 0: holes run the other way round) with polygon area >= min_area
     //    [REF pipeline.py:562-565: cv.contourArea(contour) >= area_min]
     for (uint32_t s = tid; s < nroots; s += FT) {
@@ -413,6 +632,8 @@ __global__ __launch_bounds__(FT) void blob_finish_kernel(const uint8_t *__restri
     __syncthreads();
     const uint32_t ncand = n_cand;
 
+    if (tid == 0)
+        cnts[4 + 1] = (uint32_t)wall_clock64();
     // B: RETR_EXTERNAL = not inside another outer border.  Depth at the start pixel = outer
     //    borders entered minus outer borders left on the way there along its row.
     for (uint32_t j = wave; j < ncand; j += FT / 64) {
@@ -421,17 +642,49 @@ __global__ __launch_bounds__(FT) void blob_finish_kernel(const uint8_t *__restri
         const int x0 = (int)((rk >> 2) % (uint32_t)W), y0 = (int)((rk >> 2) / (uint32_t)W);
         const uint8_t *row = m + (size_t)y0 * W;
         int d = 0;
-        for (int x = lane; x < x0; x += 64) {
-            if (row[x] == 0)
-                continue;
-            const bool wc = x == 0 || row[x - 1] == 0, ec = row[x + 1] == 0;   // x + 1 <= x0 < W
-            if (!wc && !ec)
-                continue;
-            const uint32_t e = cb[(size_t)y0 * W + x];
-            if (wc && acc[aux[parent[slot_of(e, SW)]]].a00 <= 0)
-                d++;
-            if (ec && acc[aux[parent[slot_of(e, SE)]]].a00 <= 0)
-                d--;
+        // A border can only lie inside another one through one of ITS holes: unless the
+        // start pixel is inside the bounding box of some hole border, the depth is 0 and
+        // the row is not walked at all (the usual frame: no holes, or none around a blob).
+        int boxed = 0;
+        for (uint32_t s2 = lane; s2 < nroots; s2 += 64) {
+            const BlobAcc &hb = acc[s2];
+            boxed |= hb.a00 > 0 && x0 > hb.xmin && x0 < hb.xmax && y0 > hb.ymin && y0 < hb.ymax;
+        }
+        if (__builtin_amdgcn_ballot_w64(boxed != 0) == 0) {
+            if (lane == 0) {
+                const uint32_t k = atomicAdd(&n_acc, 1u);
+                if (k < (uint32_t)kMaxBlobs) {
+                    acc_slot[k] = slot;
+                    acc_key[k] = rk;
+                } else {
+                    flags = kFlagBlobOverflow;
+                }
+            }
+            continue;
+        }
+        // eight row positions per lane and pass: their 24 byte loads are independent and in
+        // flight together; the dependent look-ups run only where a border edge was met
+        for (int xb = 0; xb < x0; xb += 64 * 8) {
+            uint8_t cc[8], ll[8], rr[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int x = xb + 64 * k + lane;
+                const bool inb = x < x0;
+                cc[k] = inb ? row[x] : (uint8_t)0;
+                ll[k] = inb && x > 0 ? row[x - 1] : (uint8_t)0;
+                rr[k] = inb ? row[x + 1] : (uint8_t)1;   // x + 1 <= x0 < W
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                if (cc[k] == 0 || (ll[k] != 0 && rr[k] != 0))
+                    continue;
+                const int x = xb + 64 * k + lane;
+                const uint32_t e = cb[(size_t)y0 * W + x];
+                if (ll[k] == 0 && acc[cslot[slot_of(e, SW)]].a00 <= 0)
+                    d++;
+                if (rr[k] == 0 && acc[cslot[slot_of(e, SE)]].a00 <= 0)
+                    d--;
+            }
         }
         d = wave_sum32(d);
         if (lane == 0 && d == 0) {
@@ -447,6 +700,8 @@ __global__ __launch_bounds__(FT) void blob_finish_kernel(const uint8_t *__restri
     __syncthreads();
     const uint32_t nacc = n_acc < (uint32_t)kMaxBlobs ? n_acc : (uint32_t)kMaxBlobs;
 
+    if (tid == 0)
+        cnts[4 + 2] = (uint32_t)wall_clock64();
     // C: cv2 returns the contours in discovery (raster) order of their start pixels = key order
     for (uint32_t j = tid; j < nacc; j += FT) {
         const uint32_t k = acc_key[j];
@@ -498,10 +753,13 @@ __global__ __launch_bounds__(FT) void blob_finish_kernel(const uint8_t *__restri
     if (nacc == 0)
         return;
 
+    if (tid == 0)
+        cnts[4 + 3] = (uint32_t)wall_clock64();
     // D: the cracks of accepted blobs, compacted
+#pragma unroll 4
     for (uint32_t c0 = 0; c0 < nc; c0 += FT) {
         const uint32_t ci = c0 + tid;
-        if (ci < nc && acc[aux[parent[ci]]].out >= 0) {
+        if (ci < nc && acc[cslot[ci]].out >= 0) {
             const uint32_t pos = atomicAdd(&n_sel, 1u);
             rsel[pos] = ci;
             cpos[ci] = pos;
@@ -510,38 +768,85 @@ __global__ __launch_bounds__(FT) void blob_finish_kernel(const uint8_t *__restri
     __syncthreads();
     const uint32_t nsel = n_sel;
 
+    if (tid == 0)
+        cnts[4 + 4] = (uint32_t)wall_clock64();
     // E: list ranking along each cycle, cut in front of its root crack.  rsum[j] ends as the
     //    number of pixel changes from crack j to the end of its cycle, so that crack j
     //    belongs to point (transitions of the cycle - rsum[j]).
+#pragma unroll 4
     for (uint32_t j = tid; j < nsel; j += FT) {
         const uint32_t ci = rsel[j], cn = succ[ci];
         rsum[j] = (key[ci] >> 2) != (key[cn] >> 2) ? 1u : 0u;
         rnxt[j] = parent[cn] == cn ? NIL : cpos[cn];
     }
     __syncthreads();
-    // pointer jumping, double-buffered: every step reads (sa, na) and writes (sb, nb)
+    if (tid == 0)
+        cnts[4 + 5] = (uint32_t)wall_clock64();
+    // pointer jumping, double-buffered: every step reads (sa, na) and writes (sb, nb).
+    // Lists of up to kLdsRank cracks (a frame's handful of people-sized blobs) are ranked
+    // in LDS as 16-bit entries; longer ones in the global scratch.
+    constexpr uint32_t kLdsRank = 3 * kMaxBlobs;   // one packed dword (sum << 16 | next) per crack
+    constexpr int PER = 3 * kMaxBlobs / FT;         // list elements per thread
+    constexpr uint32_t NIL16 = 0xffffu;
     uint32_t *sa = rsum, *na = rnxt, *sb = B.rsum2 + (size_t)img * B.cap, *nb = B.rnxt2 + (size_t)img * B.cap;
+    const bool in_lds = nsel <= kLdsRank && nsel < NIL16;
     int go = 1;
-    for (int step = 0; step < 34 && go; step++) {   // 2^32 list elements at most
-        int any = 0;
-        for (uint32_t j = tid; j < nsel; j += FT) {
-            const uint32_t n = na[j];
-            if (n != NIL) {
-                sb[j] = sa[j] + sa[n];
-                nb[j] = na[n];
-                any = 1;
-            } else {
-                sb[j] = sa[j];
-                nb[j] = NIL;
+    if (in_lds) {
+        for (uint32_t j = tid; j < nsel; j += FT)
+            pool[j] = (sa[j] << 16) | (na[j] == NIL ? NIL16 : na[j]);
+        __syncthreads();
+        for (int step = 0; step < 18 && go; step++) {
+            // every thread reads what its elements need, then all write: one buffer
+            uint32_t nv[PER];
+            int any = 0;
+#pragma unroll
+            for (int q = 0; q < PER; q++) {
+                const uint32_t j = (uint32_t)q * FT + tid;
+                nv[q] = 0;
+                if (j < nsel) {
+                    const uint32_t v = pool[j], n = v & NIL16;
+                    nv[q] = v;
+                    if (n != NIL16) {
+                        const uint32_t u = pool[n];
+                        nv[q] = (((v >> 16) + (u >> 16)) << 16) | (u & NIL16);
+                        any = 1;
+                    }
+                }
             }
+            go = __syncthreads_or(any);
+#pragma unroll
+            for (int q = 0; q < PER; q++) {
+                const uint32_t j = (uint32_t)q * FT + tid;
+                if (j < nsel)
+                    pool[j] = nv[q];
+            }
+            __syncthreads();
         }
-        go = __syncthreads_or(any);
-        uint32_t *t = sa;
-        sa = sb;
-        sb = t;
-        t = na;
-        na = nb;
-        nb = t;
+        for (uint32_t j = tid; j < nsel; j += FT)
+            sa[j] = pool[j] >> 16;
+        __syncthreads();
+    } else {
+        for (int step = 0; step < 34 && go; step++) {   // 2^32 list elements at most
+            int any = 0;
+            for (uint32_t j = tid; j < nsel; j += FT) {
+                const uint32_t n = na[j];
+                if (n != NIL) {
+                    sb[j] = sa[j] + sa[n];
+                    nb[j] = na[n];
+                    any = 1;
+                } else {
+                    sb[j] = sa[j];
+                    nb[j] = NIL;
+                }
+            }
+            go = __syncthreads_or(any);
+            uint32_t *t = sa;
+            sa = sb;
+            sb = t;
+            t = na;
+            na = nb;
+            nb = t;
+        }
     }
     if (go) {   // a list without an end: cannot happen (every cycle holds its root crack)
         if (tid == 0)
@@ -549,11 +854,14 @@ __global__ __launch_bounds__(FT) void blob_finish_kernel(const uint8_t *__restri
         return;
     }
 
+    if (tid == 0)
+        cnts[4 + 6] = (uint32_t)wall_clock64();
     // F: every crack writes its pixel into its point's place (the cracks of one run write
     //    the same value); the run that closes the cycle on the start pixel is point 0 again
+#pragma unroll 4
     for (uint32_t j = tid; j < nsel; j += FT) {
         const uint32_t ci = rsel[j];
-        const BlobAcc *a = acc + aux[parent[ci]];
+        const BlobAcc *a = acc + cslot[ci];
         const int tot = a->trans;
         const int idx = tot - (int)sa[j];
         const int np = tot > 0 ? tot : 1;
@@ -562,6 +870,9 @@ __global__ __launch_bounds__(FT) void blob_finish_kernel(const uint8_t *__restri
             points[(uint32_t)recs[a->out].point_offset + (uint32_t)idx] = (p % (uint32_t)W) | ((p / (uint32_t)W) << 16);
         }
     }
+    __syncthreads();
+    if (tid == 0)
+        cnts[4 + 7] = (uint32_t)wall_clock64();
 }
 
 }  // namespace
@@ -575,10 +886,17 @@ hipError_t blob_extract(const uint8_t *mask, const BlobBuffers &B, double min_ar
     hipError_t e = hipMemsetAsync(B.counters, 0, (size_t)B.n_img * kBlobCounters * sizeof(uint32_t), s);
     if (e != hipSuccess)
         return e;
-    const dim3 g((unsigned)((B.w + 63) / 64), (unsigned)((B.h + 3) / 4), (unsigned)B.n_img);
-    hipLaunchKernelGGL(blob_scan_kernel, g, dim3(256), 0, s, mask, B);
-    hipLaunchKernelGGL(blob_link_kernel, g, dim3(256), 0, s, mask, B);
-    // the crack count lives on the device: a fixed modest grid, grid-stride loops
+    const unsigned tiles_x = (unsigned)((B.w + TX - 1) / TX), tiles_y = (unsigned)((B.h + TY - 1) / TY);
+    if (B.seg_cap < tiles_x * tiles_y)
+        return hipErrorInvalidValue;
+    const dim3 g(tiles_x, (tiles_y + 3) / 4, (unsigned)B.n_img);
+    const int aligned = B.w % 4 == 0 && (uintptr_t)mask % 4 == 0;
+    hipLaunchKernelGGL(blob_flag_kernel, g, dim3(256), 0, s, mask, B, aligned);
+    // the tile and crack counts live on the device: fixed modest grids, grid-stride loops
+    const unsigned per_img = B.n_img >= 16 ? 64u : 256u;
+    const dim3 gt(per_img < tiles_x * tiles_y ? per_img : tiles_x * tiles_y, (unsigned)B.n_img);
+    hipLaunchKernelGGL(blob_tile_kernel, gt, dim3(256), 0, s, mask, B, aligned);
+    hipLaunchKernelGGL(blob_cross_kernel, gt, dim3(256), 0, s, mask, B);
     const dim3 g2(64, (unsigned)B.n_img);
     hipLaunchKernelGGL(blob_roots_kernel, g2, dim3(256), 0, s, B);
     hipLaunchKernelGGL(blob_stats_kernel, g2, dim3(256), 0, s, B);

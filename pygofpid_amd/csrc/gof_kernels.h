@@ -152,8 +152,8 @@ struct BlobRecord {            // == gof_blob_record (include/gofpid_hip.h)
     long long a00, a10, a01;
 };
 constexpr uint32_t kBlobHeaderWords = sizeof(BlobHeader) / 4, kBlobRecordWords = sizeof(BlobRecord) / 4;
-constexpr int kBlobCounters = 4;
-enum { kCntCracks = 0, kCntRoots = 1, kCntFlags = 2 };
+constexpr int kBlobCounters = 16;   // 0..3 counts / flags, 4.. phase stamps of the finishing kernel (100 MHz ticks)
+enum { kCntCracks = 0, kCntRoots = 1, kCntFlags = 2, kCntSegs = 3 };
 enum { kFlagCrackOverflow = 1, kFlagBlobOverflow = 2, kFlagPointOverflow = 4, kFlagInternal = 8 };
 
 struct BlobBuffers {           // device scratch for n_img masks of h x w; cap = crack slots per image
@@ -162,9 +162,11 @@ struct BlobBuffers {           // device scratch for n_img masks of h x w; cap =
     uint32_t out_words;        // dwords of one image's output block
     uint32_t *cbase;           // [n_img][h*w]  slot << 4 | side bits, for pixels that own cracks
     uint32_t *ckey;            // [n_img][cap]  pixel * 4 + side
-    uint32_t *csucc, *cparent, *caux, *cpos;   // [n_img][cap] each
+    uint32_t *csucc, *cparent, *caux, *cpos, *cslot;   // [n_img][cap] each
     uint32_t *rsel, *rnxt, *rsum, *rnxt2, *rsum2;   // [n_img][cap] each: list-ranking scratch
     BlobAcc *acc;              // [n_img][cap / 4]
+    uint32_t *segs;            // [n_img][seg_cap]  tiles (256 px x 16 rows) with foreground: ty << 16 | tx
+    uint32_t seg_cap;          // >= ceil(h / 16) * ceil(w / 256)
     uint32_t *counters;        // [n_img][kBlobCounters]
     uint32_t *out;             // [n_img][out_words]
 };

@@ -95,6 +95,9 @@ def test_extract_batch_and_1080p():
     masks[0][(yy - 500) ** 2 + (xx - 900) ** 2 < 60 ** 2] = 255                        # and an island in it
     noise = ndimage.binary_opening(rng.random((h, w)) < 0.55, np.ones((3, 3)))
     masks[1] = noise.astype(np.uint8) * 255                                            # a ragged tangle
+    masks[1, 20:24, 100:1700] = 255                                                    # and a comb: one border
+    for k in range(40):                                                                # of ~80 000 points
+        masks[1, 24:1040, 100 + 40 * k:103 + 40 * k] = 255
     for k in range(40):                                                                # people-sized boxes
         x0, y0 = int(rng.integers(0, w - 60)), int(rng.integers(0, h - 160))
         masks[2, y0:y0 + int(rng.integers(20, 160)), x0:x0 + int(rng.integers(8, 60))] = 255
