@@ -158,10 +158,11 @@ void gof_mog2_destroy(gof_mog2 *m);
 int gof_mog2_apply_host(gof_mog2 *m, const uint8_t *frames, uint8_t *masks);
 int gof_mog2_apply_dev(gof_mog2 *m, const void *d_frames, void *d_masks, void *stream);
 int gof_mog2_nframes(const gof_mog2 *m);
-/* Model as structure-of-arrays planes (the HBM layout), n = streams*h*w:
- * weight[K][n], var[K][n], mean[K][c][n] float32, modes[n] uint8.  Entries of
- * slots >= modes[i] are dead storage.  export -> host, import <- host: parity
- * tests, checkpoint/restore and warm start of a replica. */
+/* Model as structure-of-arrays planes, n = streams*h*w: weight[K][n], var[K][n],
+ * mean[K][c][n] float32, modes[n] uint8 (K = nmixtures).  Entries of slots >=
+ * modes[i] are dead storage.  (On the device a pixel's variance and means sit side by
+ * side, one 16-byte access per lane; export / import convert.)  export -> host,
+ * import <- host: parity tests, checkpoint/restore and warm start of a replica. */
 int gof_mog2_export(gof_mog2 *m, float *weight, float *var, float *mean, uint8_t *modes);
 int gof_mog2_import(gof_mog2 *m, const float *weight, const float *var, const float *mean,
                     const uint8_t *modes, int nframes);

@@ -88,6 +88,7 @@ struct gof_mog2 {
     // mean_modes run on ctx->stream and wait for it first when it is another one
     hipStream_t last = nullptr;
     DevBuf in, out;
+    DevBuf soa;              // one mode as plain planes: the staging form of export / import
     gofk::Mog2State view() const
     {
         gofk::Mog2State s;
@@ -620,6 +621,7 @@ void gof_mog2_destroy(gof_mog2 *m)
         (void)hipFree(m->state);
     m->in.release();
     m->out.release();
+    m->soa.release();
     delete m;
 }
 
@@ -678,16 +680,20 @@ int gof_mog2_export(gof_mog2 *m, float *weight, float *var, float *mean, uint8_t
     hipStream_t s = m->ctx->stream;
     const size_t n = (size_t)m->streams * m->h * m->w, np = m->np;
     const int K = m->p.nmixtures, C = m->c, F = 2 + C;
-    const float *pl = (const float *)m->state;
+    // the device keeps {variance, means} interleaved per pixel (gof_kernels.h): one mode
+    // at a time is spread into plain planes on the device and copied out plane by plane
+    int rc;
+    if ((rc = m->soa.reserve((size_t)F * n * sizeof(float))))
+        return rc;
+    float *soa = (float *)m->soa.p;
+    (void)np;
     for (int k = 0; k < K; k++) {
-        GOF_HIP(hipMemcpyAsync(weight + (size_t)k * n, pl + ((size_t)k * F + 0) * np,
-                               n * sizeof(float), hipMemcpyDeviceToHost, s));
-        GOF_HIP(hipMemcpyAsync(var + (size_t)k * n, pl + ((size_t)k * F + 1) * np,
-                               n * sizeof(float), hipMemcpyDeviceToHost, s));
-        for (int ch = 0; ch < C; ch++)
-            GOF_HIP(hipMemcpyAsync(mean + ((size_t)k * C + ch) * n,
-                                   pl + ((size_t)k * F + 2 + ch) * np, n * sizeof(float),
-                                   hipMemcpyDeviceToHost, s));
+        GOF_HIP(gofk::mog2_mode_soa(m->view(), C, k, n, soa, true, s));
+        GOF_HIP(hipMemcpyAsync(weight + (size_t)k * n, soa, n * sizeof(float), hipMemcpyDeviceToHost, s));
+        GOF_HIP(hipMemcpyAsync(var + (size_t)k * n, soa + n, n * sizeof(float), hipMemcpyDeviceToHost, s));
+        GOF_HIP(hipMemcpyAsync(mean + (size_t)k * C * n, soa + 2 * n, (size_t)C * n * sizeof(float),
+                               hipMemcpyDeviceToHost, s));
+        GOF_HIP(hipStreamSynchronize(s));   // the staging planes are reused by the next mode
     }
     GOF_HIP(hipMemcpyAsync(modes, m->view().modes, n, hipMemcpyDeviceToHost, s));
     GOF_HIP(hipStreamSynchronize(s));
@@ -709,16 +715,18 @@ int gof_mog2_import(gof_mog2 *m, const float *weight, const float *var, const fl
     for (size_t i = 0; i < n; i++)
         if (modes[i] > K)
             return fail(GOF_EINVAL, "modes[%zu] = %d exceeds nmixtures %d", i, modes[i], K);
-    float *pl = (float *)m->state;
+    int rc;
+    if ((rc = m->soa.reserve((size_t)F * n * sizeof(float))))
+        return rc;
+    float *soa = (float *)m->soa.p;
+    (void)np;
     for (int k = 0; k < K; k++) {
-        GOF_HIP(hipMemcpyAsync(pl + ((size_t)k * F + 0) * np, weight + (size_t)k * n,
-                               n * sizeof(float), hipMemcpyHostToDevice, s));
-        GOF_HIP(hipMemcpyAsync(pl + ((size_t)k * F + 1) * np, var + (size_t)k * n,
-                               n * sizeof(float), hipMemcpyHostToDevice, s));
-        for (int ch = 0; ch < C; ch++)
-            GOF_HIP(hipMemcpyAsync(pl + ((size_t)k * F + 2 + ch) * np,
-                                   mean + ((size_t)k * C + ch) * n, n * sizeof(float),
-                                   hipMemcpyHostToDevice, s));
+        GOF_HIP(hipMemcpyAsync(soa, weight + (size_t)k * n, n * sizeof(float), hipMemcpyHostToDevice, s));
+        GOF_HIP(hipMemcpyAsync(soa + n, var + (size_t)k * n, n * sizeof(float), hipMemcpyHostToDevice, s));
+        GOF_HIP(hipMemcpyAsync(soa + 2 * n, mean + (size_t)k * C * n, (size_t)C * n * sizeof(float),
+                               hipMemcpyHostToDevice, s));
+        GOF_HIP(gofk::mog2_mode_soa(m->view(), C, k, n, soa, false, s));
+        GOF_HIP(hipStreamSynchronize(s));
     }
     GOF_HIP(hipMemcpyAsync(m->view().modes, modes, n, hipMemcpyHostToDevice, s));
     GOF_HIP(hipStreamSynchronize(s));

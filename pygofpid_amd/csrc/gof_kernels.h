@@ -52,8 +52,13 @@ struct Mog2Consts {
 // most frames one launch steps through (temporal blocking)
 constexpr int kMaxT = 8;
 
-// Structure-of-arrays model in HBM, np = plane pitch in floats (>= streams*h*w):
-//   plane(m, f) = state + (m*(2+C) + f) * np ; f = 0 weight, 1 variance, 2+ch mean[ch]
+// Model in HBM, np = plane pitch in floats (>= streams*h*w, a multiple of 64).  Mode m
+// occupies the (2+C)*np floats from state + m*(2+C)*np:
+//   [0, np)            weight plane, one float per pixel
+//   [np, ...)          VECTOR plane, {variance, mean[0], ...} of a pixel side by side:
+//                      float2 (C = 1) or float4 {var, mean0, mean1, mean2} (C = 3, 4)
+//   [5 np, 6 np)       mean[3] plane (C = 4 only)
+// so that a pixel's variance and means travel as one 8- / 16-byte access per lane.
 struct Mog2State {
     float *planes;
     uint8_t *modes;
@@ -125,6 +130,11 @@ hipError_t morph_rect_chain(const uint8_t *src, uint8_t *dst, int n_img, int h, 
                             const RectChain &ch, bool chain_valued, hipStream_t s,
                             const uint8_t *rowflags = nullptr, int streams = 1);
 bool morph_rect_chain_supported(const RectChain &ch);
+
+// One mode between the HBM layout and structure-of-arrays planes soa[f * n + i] (f = 0
+// weight, 1 variance, 2 + ch mean[ch]; n pixels): the form export / import exchange.
+hipError_t mog2_mode_soa(const Mog2State &st, int c, int mode, size_t n, float *soa, bool to_soa,
+                         hipStream_t s);
 
 // (h,w,c in {3,4}) -> (h,w) luma, BGR order unless rgb
 hipError_t cvt_gray(const uint8_t *src, uint8_t *dst, int n_img, int h, int w, int c, bool rgb,

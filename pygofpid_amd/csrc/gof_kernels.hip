@@ -82,6 +82,44 @@ __device__ __forceinline__ void swap_modes(PixelModel<C> &M, int i, bool doit)
     }
 }
 
+// Model layout in HBM (gof_kernels.h, Mog2State): per mode a weight plane and a VECTOR
+// plane that holds {variance, mean[0..]} of a pixel side by side -- float4 for BGR, so the
+// 16 bytes a settled pixel updates per frame are ONE global_load_dwordx4 / store_dwordx4
+// per lane (1 KiB per wave-instruction) instead of four dword streams; float2 for grey;
+// float4 + a fifth plane for 4-channel frames.  `mode` = first float of the mode's planes,
+// `pix` = pixel index (wave-uniform row offset + lane).
+template <int C>
+__device__ __forceinline__ void load_mode_vec(const float *mode, size_t np, size_t pix, float &var,
+                                              float (&mu)[C])
+{
+    if (C == 1) {
+        const float2 q = ((const float2 *)(mode + np))[pix];
+        var = q.x;
+        mu[0] = q.y;
+    } else {
+        const float4 q = ((const float4 *)(mode + np))[pix];
+        var = q.x;
+        mu[0] = q.y;
+        mu[1 % C] = q.z;
+        mu[2 % C] = q.w;
+        if (C == 4)
+            mu[3 % C] = (mode + 5 * np)[pix];
+    }
+}
+
+template <int C>
+__device__ __forceinline__ void store_mode_vec(float *mode, size_t np, size_t pix, float var,
+                                               const float (&mu)[C])
+{
+    if (C == 1) {
+        ((float2 *)(mode + np))[pix] = make_float2(var, mu[0]);
+    } else {
+        ((float4 *)(mode + np))[pix] = make_float4(var, mu[0], mu[1 % C], mu[2 % C]);
+        if (C == 4)
+            (mode + 5 * np)[pix] = mu[3 % C];
+    }
+}
+
 // IEEE-correct a / b for operands in the normal range with a normal quotient:
 // the Newton / residual chain hipcc itself emits for a float division, without
 // its range scaling (v_div_scale, v_div_fmas' scale) and special-case fix-up
@@ -535,6 +573,7 @@ __global__ __launch_bounds__(256, (!MULTI && ALN && C <= 3) ? 8 : 1) void mog2_k
     const bool valid = rowok && x < W;
     const unsigned xl = valid ? (unsigned)x : 0u;           // lane offset within the row
     const size_t rowoff = (size_t)img * N + (size_t)yy * W; // wave-uniform
+    float *const planes_ = planes;
     float *const prow = planes + rowoff;
     PixelModel<C> M;
     // the mode-count byte also says (bit 7, kW0One) that the first mode's weight is
@@ -542,10 +581,7 @@ __global__ __launch_bounds__(256, (!MULTI && ALN && C <= 3) ? 8 : 1) void mog2_k
     // all say so does not read the weight plane at all
     const int mbyte_in = valid ? (int)modes[rowoff + xl] : 0;
     int nmodes = mbyte_in & kModeCount;
-    M.var[0] = (prow + np)[xl];
-#pragma unroll
-    for (int c = 0; c < C; c++)
-        M.mu[0][c] = (prow + (size_t)(2 + c) * np)[xl];
+    load_mode_vec<C>(planes_, np, rowoff + xl, M.var[0], M.mu[0]);
     M.w[0] = 1.f;
     if (__builtin_amdgcn_ballot_w64(valid && !(mbyte_in & kW0One)) != 0)
         M.w[0] = prow[xl];
@@ -555,12 +591,9 @@ __global__ __launch_bounds__(256, (!MULTI && ALN && C <= 3) ? 8 : 1) void mog2_k
 #pragma unroll
         for (int m = 1; m < kMaxModes; m++) {
             if (m < nmodes) {
-                const float *pm = prow + (size_t)m * F * np;
-                M.w[m] = pm[xl];
-                M.var[m] = (pm + np)[xl];
-#pragma unroll
-                for (int c = 0; c < C; c++)
-                    M.mu[m][c] = (pm + (size_t)(2 + c) * np)[xl];
+                const float *pm = planes_ + (size_t)m * F * np;
+                M.w[m] = pm[rowoff + xl];
+                load_mode_vec<C>(pm, np, rowoff + xl, M.var[m], M.mu[m]);
             } else {
                 M.w[m] = 0.f;
                 M.var[m] = 0.f;
@@ -735,13 +768,10 @@ __global__ __launch_bounds__(256, (!MULTI && ALN && C <= 3) ? 8 : 1) void mog2_k
 #pragma unroll
     for (int m = 0; m < kMaxModes; m++) {
         if (m < nmodes) {
-            float *pm = prow + (size_t)m * F * np;
+            float *pm = planes_ + (size_t)m * F * np;
             if (m > 0 || w0_dirty)
-                pm[xl] = M.w[m];
-            (pm + np)[xl] = M.var[m];
-#pragma unroll
-            for (int c = 0; c < C; c++)
-                (pm + (size_t)(2 + c) * np)[xl] = M.mu[m][c];
+                pm[rowoff + xl] = M.w[m];
+            store_mode_vec<C>(pm, np, rowoff + xl, M.var[m], M.mu[m]);
         }
     }
     if (nm_dirty)
@@ -982,15 +1012,13 @@ __global__ __launch_bounds__(256) void mog2_frames_kernel(const Mog2FramesArgs a
     const int yy = y < H ? y : 0;
     const unsigned xl = valid ? (unsigned)x : 0u;
     const size_t rowoff = (size_t)img * N + (size_t)yy * W;   // wave-uniform
+    float *const planes_ = a.planes;
     float *const prow = a.planes + rowoff;
     const size_t np = a.np;
     PixelModel<C> M;
     const int mbyte_in = (int)a.modes[rowoff + xl];   // mode count | kW0One (see mog2_kernel)
     int nmodes = mbyte_in & kModeCount;
-    M.var[0] = (prow + np)[xl];
-#pragma unroll
-    for (int c = 0; c < C; c++)
-        M.mu[0][c] = (prow + (size_t)(2 + c) * np)[xl];
+    load_mode_vec<C>(planes_, np, rowoff + xl, M.var[0], M.mu[0]);
     M.w[0] = 1.f;
     if (__builtin_amdgcn_ballot_w64(!(mbyte_in & kW0One)) != 0)
         M.w[0] = prow[xl];
@@ -1003,12 +1031,9 @@ __global__ __launch_bounds__(256) void mog2_frames_kernel(const Mog2FramesArgs a
 #pragma unroll
         for (int m = 1; m < kMaxModes; m++) {
             if (m < nmodes) {
-                const float *pm = prow + (size_t)m * F * np;
-                M.w[m] = pm[xl];
-                M.var[m] = (pm + np)[xl];
-#pragma unroll
-                for (int c = 0; c < C; c++)
-                    M.mu[m][c] = (pm + (size_t)(2 + c) * np)[xl];
+                const float *pm = planes_ + (size_t)m * F * np;
+                M.w[m] = pm[rowoff + xl];
+                load_mode_vec<C>(pm, np, rowoff + xl, M.var[m], M.mu[m]);
             } else {
                 M.w[m] = 0.f;
                 M.var[m] = 0.f;
@@ -1147,13 +1172,10 @@ __global__ __launch_bounds__(256) void mog2_frames_kernel(const Mog2FramesArgs a
 #pragma unroll
     for (int m = 0; m < kMaxModes; m++) {
         if (m < nmodes) {
-            float *pm = prow + (size_t)m * F * np;
+            float *pm = planes_ + (size_t)m * F * np;
             if (m > 0 || w0_dirty)
-                pm[xl] = M.w[m];
-            (pm + np)[xl] = M.var[m];
-#pragma unroll
-            for (int c = 0; c < C; c++)
-                (pm + (size_t)(2 + c) * np)[xl] = M.mu[m][c];
+                pm[rowoff + xl] = M.w[m];
+            store_mode_vec<C>(pm, np, rowoff + xl, M.var[m], M.mu[m]);
         }
     }
     if (nm_dirty)
@@ -1977,6 +1999,34 @@ __global__ __launch_bounds__(256) void gray_kernel(const uint8_t *__restrict__ s
     dst[i] = (uint8_t)((p[0] * c0 + p[1] * c1 + p[2] * c2 + (1 << 13)) >> 14);
 }
 
+// One mode of the model between its HBM layout (weight plane + vector plane, see
+// load_mode_vec) and plain structure-of-arrays planes soa[f * n + i], f = 0 weight,
+// 1 variance, 2 + c mean[c]: what gof_mog2_export / import hand to the host.
+template <int C, bool TO_SOA>
+__global__ __launch_bounds__(256) void mode_soa_kernel(float *__restrict__ mode, size_t np, size_t n,
+                                                       float *__restrict__ soa)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n)
+        return;
+    float var, mu[C];
+    if (TO_SOA) {
+        load_mode_vec<C>(mode, np, i, var, mu);
+        soa[i] = mode[i];
+        soa[n + i] = var;
+#pragma unroll
+        for (int c = 0; c < C; c++)
+            soa[(size_t)(2 + c) * n + i] = mu[c];
+    } else {
+        var = soa[n + i];
+#pragma unroll
+        for (int c = 0; c < C; c++)
+            mu[c] = soa[(size_t)(2 + c) * n + i];
+        mode[i] = soa[i];
+        store_mode_vec<C>(mode, np, i, var, mu);
+    }
+}
+
 __global__ __launch_bounds__(256) void sum_modes_kernel(const uint8_t *__restrict__ modes, size_t n,
                                                         unsigned long long *out)
 {
@@ -2294,6 +2344,30 @@ hipError_t cvt_gray(const uint8_t *src, uint8_t *dst, int n_img, int h, int w, i
     const int B2Y = 1868, G2Y = 9617, R2Y = 4899;
     hipLaunchKernelGGL(gray_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, dst, npix, c,
                        rgb ? R2Y : B2Y, G2Y, rgb ? B2Y : R2Y);
+    return hipGetLastError();
+}
+
+hipError_t mog2_mode_soa(const Mog2State &st, int c, int mode, size_t n, float *soa, bool to_soa,
+                         hipStream_t s)
+{
+    if (n < 1 || n > st.np || mode < 0 || mode >= kMaxModes || !soa)
+        return hipErrorInvalidValue;
+    float *mp = st.planes + (size_t)mode * (2 + c) * st.np;
+    const dim3 g((unsigned)((n + 255) / 256));
+#define GOF_SOA(CC)                                                                              \
+    do {                                                                                         \
+        if (to_soa)                                                                              \
+            hipLaunchKernelGGL((mode_soa_kernel<CC, true>), g, dim3(256), 0, s, mp, st.np, n, soa);  \
+        else                                                                                     \
+            hipLaunchKernelGGL((mode_soa_kernel<CC, false>), g, dim3(256), 0, s, mp, st.np, n, soa); \
+    } while (0)
+    switch (c) {
+    case 1: GOF_SOA(1); break;
+    case 3: GOF_SOA(3); break;
+    case 4: GOF_SOA(4); break;
+    default: return hipErrorInvalidValue;
+    }
+#undef GOF_SOA
     return hipGetLastError();
 }
 
