@@ -985,8 +985,10 @@ struct Mog2FramesArgs {
     Mog2Consts k;
 };
 
+// (7 waves per SIMD for BGR: the issue-bound launch needs every one of them; the float4
+// model loads alone would let the allocator drift to 74 registers = 6 waves, 8 % slower)
 template <int C>
-__global__ __launch_bounds__(256) void mog2_frames_kernel(const Mog2FramesArgs a)
+__global__ __launch_bounds__(256, C <= 3 ? 7 : 1) void mog2_frames_kernel(const Mog2FramesArgs a)
 {
     constexpr int F = 2 + C;
     typedef FrameTiles<C> Tiles;
@@ -1026,6 +1028,9 @@ __global__ __launch_bounds__(256) void mog2_frames_kernel(const Mog2FramesArgs a
     // slots 1.. are loaded only if some pixel of the wave has them; otherwise slot 1
     // starts empty (the single-mode loops may fill it) and slots 2.. stay untouched
     // until the general loop is entered
+    // the staged rows go to LDS before the further modes are asked for: the 16 staging
+    // registers are free again by then (settled waves, four in five, load no further mode)
+    Tiles::store(tiles, wave, lane, raw);
     const bool multi_in = __builtin_amdgcn_ballot_w64(nmodes > 1) != 0;
     if (multi_in) {
 #pragma unroll
@@ -1050,7 +1055,6 @@ __global__ __launch_bounds__(256) void mog2_frames_kernel(const Mog2FramesArgs a
             M.mu[1][c] = 0.f;
     }
 
-    Tiles::store(tiles, wave, lane, raw);
 
     // lane-invariant tap patterns; a lane outside the image shadows the tile's first pixel
     TapPatterns<C> taps;
