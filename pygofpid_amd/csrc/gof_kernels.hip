@@ -475,8 +475,10 @@ __device__ __forceinline__ int reflect1(int p, int len)
 // ALN = true: every staged frame row starts at the same byte offset mod 4 (row
 // pitch and frame pitch multiples of 4, 4-byte aligned base -- the launcher
 // checks), so the lane's window addresses and byte shifts are loop invariants.
-template <int C, bool BLUR3, bool MULTI, bool ALN>
-__global__ __launch_bounds__(256, (!MULTI && ALN && C <= 3) ? 8 : 1) void mog2_kernel(const uint8_t *__restrict__ frame,
+// TR = rows per tile = waves per workgroup (64 * TR threads): 4 everywhere except the
+// tile-size sweep of the per-frame form (profiles/micro/tile_sweep.py, GOF_T1_TILE_ROWS).
+template <int C, bool BLUR3, bool MULTI, bool ALN, int TR = TH>
+__global__ __launch_bounds__(64 * TR, (!MULTI && ALN && C <= 3) ? 8 : 1) void mog2_kernel(const uint8_t *__restrict__ frame,
                                                    uint8_t *__restrict__ mask,
                                                    float *__restrict__ planes,
                                                    uint8_t *__restrict__ modes, size_t np, int H,
@@ -490,16 +492,16 @@ __global__ __launch_bounds__(256, (!MULTI && ALN && C <= 3) ? 8 : 1) void mog2_k
     const int lane = threadIdx.x & 63;
     // wave-uniform values are forced into SGPRs: row index, row bases, plane bases
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TR;
     const int img = blockIdx.z;
     const int x = x0 + lane, y = y0 + wave;
     const size_t N = (size_t)H * W;
 
-    // raw (TH+2) x (TW+2) px input tiles of ALL frames of the launch (<= 10 KB):
+    // raw (TR+2) x (TW+2) px input tiles of ALL frames of the launch (<= 10 KB):
     // every global load of the kernel is issued up front, one barrier, and the
     // frame loop below touches only LDS and registers
     constexpr int ROWD = ((TW + 2) * C + 3 + 3) / 4 + 1;   // + misalignment slack + read-ahead of px()
-    constexpr int TILE = (TH + 2) * ROWD;
+    constexpr int TILE = (TR + 2) * ROWD;
     constexpr int NT = MULTI ? kMaxT : 1;
     __shared__ uint32_t tiles[BLUR3 ? NT * TILE : 1];
     const int sx0 = x0 > 0 ? x0 - 1 : 0;
@@ -517,8 +519,8 @@ __global__ __launch_bounds__(256, (!MULTI && ALN && C <= 3) ? 8 : 1) void mog2_k
                 const uint8_t *fimg = frame + (size_t)ti * frame_stride + (size_t)img * N * C;
 #pragma unroll
                 for (int rr = 0; rr < 2; rr++) {
-                    const int r = wave + 4 * rr;
-                    const int gy = reflect1(y0 - 1 + (r < TH + 2 ? r : 0), H);
+                    const int r = wave + TR * rr;
+                    const int gy = reflect1(y0 - 1 + (r < TR + 2 ? r : 0), H);
                     const int gyc = gy < H ? gy : H - 1;   // rows below a ragged last tile
                     const uint8_t *a = fimg + ((size_t)gyc * W + sx0) * C;
                     const int mis = (int)((uintptr_t)a & 3);
@@ -552,8 +554,8 @@ __global__ __launch_bounds__(256, (!MULTI && ALN && C <= 3) ? 8 : 1) void mog2_k
             if (ti < T) {
 #pragma unroll
                 for (int rr = 0; rr < 2; rr++) {
-                    const int r = wave + 4 * rr;
-                    if (r < TH + 2) {
+                    const int r = wave + TR * rr;
+                    if (r < TR + 2) {
 #pragma unroll
                         for (int q = 0; q < NDW; q++) {
                             const int d = lane + 64 * q;
@@ -2126,13 +2128,33 @@ hipError_t mog2_apply(const uint8_t *frame, uint8_t *mask, const Mog2State &st, 
         }
         return hipGetLastError();
     }
+    // A/B knob of the LDS tile-size sweep (BASELINE config 3): rows per tile of the per-frame
+    // BGR kernel, 2 | 4 | 8 (64 px wide, one wave per row)
+    // Default 2: the sweep (profiles/r02_tile_sweep.txt) has 2 rows ahead of 4 and 8 at
+    // 2160p (151 / 155 / 167 us) and level at 1080p -- more, smaller workgroups balance
+    // better than the halo rows they re-read cost (those come from L2).
+    static const int tile_rows = [] {
+        const char *e = getenv("GOF_T1_TILE_ROWS");
+        const int v = e ? atoi(e) : 2;
+        return v == 2 || v == 8 ? v : TH;
+    }();
 #define GOF_LAUNCH_MOG2_(CC, BB, MM, AA)                                                         \
     hipLaunchKernelGGL((mog2_kernel<CC, BB, MM, AA>), g, dim3(256), 0, s, frame, mask,           \
                        st.planes, st.modes, st.np, h, w, T, fstride, mstride, k, kx, ky, rowflags,      \
                        rowflag_pitch(w), frame_end)
 #define GOF_LAUNCH_MOG2(CC, BB)                                                                  \
     do {                                                                                         \
-        if (T == 1 && aln)                                                                       \
+        if (T == 1 && aln && (BB) && CC == 3 && tile_rows != TH) {                               \
+            const dim3 gr = grid3(w, h, n_img, TW, tile_rows);                                   \
+            if (tile_rows == 2)                                                                  \
+                hipLaunchKernelGGL((mog2_kernel<3, true, false, true, 2>), gr, dim3(128), 0, s, frame, mask, \
+                                   st.planes, st.modes, st.np, h, w, T, fstride, mstride, k, kx, ky,  \
+                                   rowflags, rowflag_pitch(w), frame_end);                       \
+            else                                                                                 \
+                hipLaunchKernelGGL((mog2_kernel<3, true, false, true, 8>), gr, dim3(512), 0, s, frame, mask, \
+                                   st.planes, st.modes, st.np, h, w, T, fstride, mstride, k, kx, ky,  \
+                                   rowflags, rowflag_pitch(w), frame_end);                       \
+        } else if (T == 1 && aln)                                                                \
             GOF_LAUNCH_MOG2_(CC, BB, false, (BB));                                               \
         else if (T == 1)                                                                         \
             GOF_LAUNCH_MOG2_(CC, BB, false, false);                                              \
