@@ -938,6 +938,21 @@ struct TapPatterns {
     __device__ __forceinline__ void blur(const uint32_t *tiles, uint32_t wa, const uint32_t (&ky)[3],
                                          uint32_t half, bool batch, uint32_t (&out)[C]) const
     {
+#ifdef GOF_ABLATE_BLUR
+        // timing ablation only (profiles/): the centre row's first three window bytes instead
+        // of the blurred pixel -- bounds what a free blur would buy; results are NOT the path's
+        {
+            const uint32_t *q = (const uint32_t *)((const char *)tiles + wa + (uint32_t)ROWD * 4u);
+            const uint32_t v = q[0];
+#pragma unroll
+            for (int c = 0; c < C; c++)
+                out[c] = (v >> (8 * (c & 3))) & 255u;
+            (void)ky;
+            (void)half;
+            (void)batch;
+            return;
+        }
+#endif
         uint32_t win[3][3];
 #pragma unroll
         for (int j = 0; j < 3; j++) {
