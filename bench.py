@@ -42,6 +42,7 @@ Prints ONE JSON line on rank 0, with
                    Every frac is <= 1 by construction of its roofline.
   per_frame     -- the same path with ONE frame per launch (what GOFPID.detect()
                    runs), whole-step timed by the same protocol + its kernel record
+  detect_path   -- steps 1-3 + the GPU blob extraction of step 4 on every mask of a step
   worst_case    -- reference-test style input (i.i.d. uniform uint8 frames,
                    /root/reference/tests/test_pipeline.py:98-109): every pixel carries
                    all 5 modes (206 B/px/frame), nothing is ever "settled"
@@ -165,6 +166,7 @@ class Runner:
         self.frames, self.masks, self.T, self.P = frames, masks, T, frames.shape[0]
         self.red_dev = red_dev
         self.i = 0
+        self.post = None      # enqueued after every step (the blob extraction of the detect-path block)
 
     def step(self, T=None):
         T = T or self.T
@@ -172,6 +174,8 @@ class Runner:
         if base + T > self.P:
             base = 0
         self.pipe.apply_device(self.frames[base].data_ptr(), self.masks.data_ptr(), n_frames=T)
+        if self.post:
+            self.post(T)
         self.i += 1
 
     def sync(self):
@@ -438,6 +442,31 @@ def main():
                         "ms_per_step": s1["ms_per_step"], "round_ms": s1["round_ms"],
                         "frames_per_step": S * world})
             out["per_frame"] = rec
+
+    # steps 1-3 + step 4's front end on the device (contours, area filter, blob moments of every
+    # mask; pygofpid/helpers.py:125-168, pipeline.py:555-572): what a batch caller of detect() runs
+    if not args.no_extra and not args.noise and world == 1 and not args.no_events:
+        from pygofpid_amd.blobs import BlobExtractor
+        ex = BlobExtractor(T * S, h, w, ctx=ctx)
+        run.post = lambda t: ex.extract_device(masks.data_ptr(), t * S, 100.0)
+        run.preroll(0.1, 32)
+        elb = run.rounds(K, R)
+        sb = summarize_rounds(elb, K, S * T)
+        res = [ex.result(i) for i in range(T * S)]
+        run.post = None
+        ok = [r for r in res if r is not None]
+        out["detect_path"] = {
+            "what": "steps 1-3 + GPU blob extraction (external contours, cv.contourArea >= 100, moments, "
+                    "bounding boxes, ordered contour points) on all %d masks of a step; only blob records "
+                    "and contour points are copied to the host" % (T * S),
+            "value": sb["frames_per_s"], "unit_value": "frames/s", "ms_per_step": sb["ms_per_step"],
+            "round_ms": sb["round_ms"],
+            "blobs_per_mask": round(sum(len(r[0]) for r in ok) / max(1, len(ok)), 2),
+            "contour_points_per_mask": round(sum(len(r[1]) for r in ok) / max(1, len(ok)), 1),
+            "bytes_to_host_per_mask": round(sum(16 + r[0].nbytes + 4 * len(r[1]) for r in ok) / max(1, len(ok)), 1),
+            "masks_without_result": len(res) - len(ok),
+        }
+        del ex
 
     # worst case: uniform-noise input, every pixel carries all five modes
     if not args.no_extra and not args.noise and world == 1 and not args.no_events:
