@@ -78,12 +78,20 @@ __device__ __forceinline__ uint32_t uf_find(uint32_t *parent, uint32_t i, uint32
     return i;
 }
 
-__device__ __forceinline__ void uf_union(uint32_t *parent, const uint32_t *key, uint32_t a, uint32_t b,
-                                         uint32_t *flags)
+// Union for K2, where the trees are shallow (a crack points at its tile's local root,
+// roots at roots of neighbouring tiles): both walks advance together, one round trip to the
+// memory side per step instead of two, and nothing is re-pointed on the way (K3 flattens).
+__device__ __forceinline__ void uf_union_pair(uint32_t *parent, const uint32_t *key, uint32_t a, uint32_t b,
+                                              uint32_t *flags)
 {
     for (int it = 0; it < kMaxUnionTries; it++) {
-        a = uf_find(parent, a, flags);
-        b = uf_find(parent, b, flags);
+        for (int st = 0; st < kMaxFindSteps; st++) {
+            const uint32_t pa = ld_parent(parent + a), pb = ld_parent(parent + b);
+            if (pa == a && pb == b)
+                break;
+            a = pa;
+            b = pb;
+        }
         if (a == b)
             return;
         if (key[a] > key[b]) {
@@ -91,7 +99,6 @@ __device__ __forceinline__ void uf_union(uint32_t *parent, const uint32_t *key, 
             a = b;
             b = t;
         }
-        // a has the smaller key: hang b under it, if b is still a root
         if (cas_parent(parent + b, b, a))
             return;
     }
@@ -116,11 +123,6 @@ __device__ __forceinline__ Nbr load_nbr(const uint8_t *m, int x, int y, int W, i
     b.sw = dn && lf && r[W - 1] != 0;
     b.se = dn && rt && r[W + 1] != 0;
     return b;
-}
-
-__device__ __forceinline__ unsigned sides_of(const Nbr &b)
-{
-    return (b.n ? 0u : 1u << SN) | (b.w ? 0u : 1u << SW) | (b.s ? 0u : 1u << SS) | (b.e ? 0u : 1u << SE);
 }
 
 // ---- K0: which tiles hold any foreground ----------------------------------------------------
@@ -205,7 +207,12 @@ __device__ __forceinline__ void successor(const Nbr &b, unsigned s, int &dx, int
 // smallest local slot of a cycle part is its smallest key.  Links that stay inside the tile
 // are united in LDS (no global atomics); links that leave it are left to K2.
 constexpr int TBW = TX + 8;            // LDS row: 4 px to the left (one dword) .. 4 px to the right
-constexpr int kTileCracks = 2 * TX * TY;   // no tile has more border edges than two per pixel
+// Border edges of a tile united in LDS.  A tile a morphological open / close has smoothed
+// carries a few hundred; one with more than this (raw noise: up to two per pixel) leaves
+// ALL its links to K2 (kBigTile in its list entry) -- so that the LDS footprint, and with it
+// the number of tiles in flight per CU, is set by the common case, not by the worst.
+constexpr int kTileCracks = 2048;
+constexpr uint32_t kBigTile = 0x8000u;   // list entry: ty << 16 | kBigTile? | tx  (tx <= 255)
 
 __device__ __forceinline__ uint32_t lds_find(uint32_t *lp, uint32_t i)
 {
@@ -236,13 +243,13 @@ __global__ __launch_bounds__(256) void blob_tile_kernel(const uint8_t *__restric
     const uint8_t *m = mask + (size_t)img * N;
     uint32_t *cnts = B.counters + (size_t)img * kBlobCounters;
     const uint32_t ntile = cnts[kCntSegs];
-    const uint32_t *wl = B.segs + (size_t)img * B.seg_cap;
+    uint32_t *wl = B.segs + (size_t)img * B.seg_cap;
     uint32_t *cb = B.cbase + (size_t)img * N;
     uint32_t *key = B.ckey + (size_t)img * B.cap, *parent = B.cparent + (size_t)img * B.cap,
              *succ = B.csucc + (size_t)img * B.cap;
     for (uint32_t t = blockIdx.x; t < ntile; t += gridDim.x) {
         const uint32_t ent = wl[t];
-        const int x0 = (int)(ent & 0xffffu) * TX, y0 = (int)(ent >> 16) * TY;
+        const int x0 = (int)(ent & 0x7fffu) * TX, y0 = (int)(ent >> 16) * TY;
         __syncthreads();   // (LDS of the previous tile is no longer read)
         // 1. tile + frame into LDS; outside the image = background
         for (int i = tid; i < (TY + 2) * (TBW / 4); i += 256) {
@@ -307,25 +314,37 @@ __global__ __launch_bounds__(256) void blob_tile_kernel(const uint8_t *__restric
             continue;
         }
         // 4. slots: local table for the links below, global table for K2 and the later kernels
+        const bool big = total > (unsigned)kTileCracks;
         uint32_t loff = woff + inc - cnt;
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             const unsigned sd = (unsigned)(sides64 >> (4 * k)) & 15u;
             if (sd) {
                 const int lx = 16 * q + k;
-                lbase[r * TX + lx] = (uint16_t)loff;
+                if (!big)
+                    lbase[r * TX + lx] = (uint16_t)loff;
                 const uint32_t pix = (uint32_t)(y0 + r) * W + (uint32_t)(x0 + lx);
                 cb[pix] = ((base + loff) << 4) | sd;
 #pragma unroll
                 for (unsigned sdx = 0; sdx < 4; sdx++) {
                     if (sd & (1u << sdx)) {
                         key[base + loff] = pix * 4u + sdx;
-                        lkey[loff] = (uint16_t)(((r * TX + lx) << 2) | sdx);
-                        lparent[loff] = loff;
+                        if (big) {   // every crack its own root, every link K2's
+                            parent[base + loff] = base + loff;
+                            succ[base + loff] = NIL;
+                        } else {
+                            lkey[loff] = (uint16_t)(((r * TX + lx) << 2) | sdx);
+                            lparent[loff] = loff;
+                        }
                         loff++;
                     }
                 }
             }
+        }
+        if (big) {
+            if (tid == 0)
+                wl[t] = ent | kBigTile;
+            continue;
         }
         __syncthreads();
         // 5. links, one crack per thread and pass (a thread's own 16 pixels may all be border
@@ -402,11 +421,15 @@ __global__ __launch_bounds__(256) void blob_cross_kernel(const uint8_t *__restri
     uint32_t *succ = B.csucc + (size_t)img * B.cap, *parent = B.cparent + (size_t)img * B.cap;
     for (uint32_t t = blockIdx.x; t < ntile; t += gridDim.x) {
         const uint32_t ent = wl[t];
-        const int x0 = (int)(ent & 0xffffu) * TX, y0 = (int)(ent >> 16) * TY;
+        const int x0 = (int)(ent & 0x7fffu) * TX, y0 = (int)(ent >> 16) * TY;
+        const bool big = (ent & kBigTile) != 0;   // K1 united nothing in this tile: all its pixels, all links
         // border pixels: 256 of row 0, 256 of row 15, 14 + 14 of columns 0 and 255
-        for (int i = tid; i < 2 * TX + 2 * (TY - 2); i += 256) {
+        for (int i = tid; i < (big ? TX * TY : 2 * TX + 2 * (TY - 2)); i += 256) {
             int lx, ly;
-            if (i < TX) {
+            if (big) {
+                lx = i & (TX - 1);
+                ly = i >> 8;   // TX == 256
+            } else if (i < TX) {
                 lx = i;
                 ly = 0;
             } else if (i < 2 * TX) {
@@ -421,7 +444,7 @@ __global__ __launch_bounds__(256) void blob_cross_kernel(const uint8_t *__restri
             if (x >= W || y >= H || m[(size_t)y * W + x] == 0)
                 continue;
             const Nbr b = load_nbr(m, x, y, W, H);
-            const unsigned sd = sides_of(b);
+            const unsigned sd = (b.n ? 0u : 1u << SN) | (b.w ? 0u : 1u << SW) | (b.s ? 0u : 1u << SS) | (b.e ? 0u : 1u << SE);
             if (!sd)
                 continue;
             const uint32_t pix = (uint32_t)y * W + x;
@@ -433,12 +456,12 @@ __global__ __launch_bounds__(256) void blob_cross_kernel(const uint8_t *__restri
                 unsigned ns;
                 successor(b, sdx, dx, dy, ns);
                 const int nx = lx + dx, ny = ly + dy;
-                if (nx >= 0 && nx < TX && ny >= 0 && ny < TY)
+                if (!big && nx >= 0 && nx < TX && ny >= 0 && ny < TY)
                     continue;   // stayed inside: K1 did it
                 const uint32_t ci = slot_of(e, sdx);
                 const uint32_t cn = slot_of(cb[(int)pix + dy * W + dx], ns);
                 succ[ci] = cn;
-                uf_union(parent, key, ci, cn, cnts + kCntFlags);
+                uf_union_pair(parent, key, ci, cn, cnts + kCntFlags);
             }
         }
     }
