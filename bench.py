@@ -314,6 +314,12 @@ def main():
     ap.add_argument("--noise", action="store_true", help="main workload on the worst-case input instead")
     args = ap.parse_args()
 
+    # Everything but the final JSON line goes to stderr: RCCL prints a version banner on
+    # stdout when its first communicator is created, libraries may print warnings.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
 
     from pygofpid_amd import distributed as gd
@@ -503,8 +509,11 @@ def main():
         if args.cpu_seconds > 0 and world == 1:   # CPU leg: rank 0 at N = 1 only
             host = [frames[i, 0].cpu().numpy() for i in range(min(32, frames.shape[0]))]
             out["cpu_baseline"] = cpu_baseline(host, h, w, args.cpu_seconds)
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
-    if world > 1:
+        os.dup2(2, 1)
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
         gd.barrier()
         torch.distributed.destroy_process_group()
 

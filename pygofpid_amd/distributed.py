@@ -32,8 +32,8 @@ def env_rank():
 def init(backend=None, device=None):
     """Join the process group if WORLD_SIZE > 1.  Returns (rank, world)."""
     rank, world, _ = env_rank()
-    if world == 1:
-        return 0, 1
+    if world == 1 and not os.environ.get("GOF_DIST_FORCE"):
+        return 0, 1      # (GOF_DIST_FORCE=1: a one-rank group, to rehearse the RCCL calls on one GPU)
     import torch.distributed as dist
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
