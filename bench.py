@@ -166,16 +166,18 @@ class Runner:
         self.frames, self.masks, self.T, self.P = frames, masks, T, frames.shape[0]
         self.red_dev = red_dev
         self.i = 0
-        self.post = None      # enqueued after every step (the blob extraction of the detect-path block)
+        self.pre = None       # step index -> device pointer of the masks to write (default: self.masks)
+        self.post = None      # (step index, T): enqueued after every step (the detect-path block's extraction)
 
     def step(self, T=None):
         T = T or self.T
         base = (self.i * T) % self.P
         if base + T > self.P:
             base = 0
-        self.pipe.apply_device(self.frames[base].data_ptr(), self.masks.data_ptr(), n_frames=T)
+        mptr = self.pre(self.i) if self.pre else self.masks.data_ptr()
+        self.pipe.apply_device(self.frames[base].data_ptr(), mptr, n_frames=T)
         if self.post:
-            self.post(T)
+            self.post(self.i, T)
         self.i += 1
 
     def sync(self):
@@ -454,17 +456,41 @@ def main():
     if not args.no_extra and not args.noise and world == 1 and not args.no_events:
         from pygofpid_amd.blobs import BlobExtractor
         ex = BlobExtractor(T * S, h, w, ctx=ctx)
-        run.post = lambda t: ex.extract_device(masks.data_ptr(), t * S, 100.0)
+        # The extraction is latency-bound (union-find, list ranking), the detector launch
+        # issue-bound: they overlap.  Masks are double-buffered; the extraction of step i runs
+        # on a second HIP stream while the pipeline's stream computes step i + 1.
+        masks2 = [masks[:T], torch.empty_like(masks[:T])]
+        s_pipe = torch.cuda.ExternalStream(ctx.stream, device=device)
+        s_blob = torch.cuda.Stream(device=device, priority=-1)   # its small grids must not queue behind 64 800 workgroups
+        done = [torch.cuda.Event(), torch.cuda.Event()]      # masks2[k] written
+        free = [torch.cuda.Event(), torch.cuda.Event()]      # masks2[k] read by its extraction
+        for e in free:
+            e.record(s_blob)
+
+        def pre(i):
+            s_pipe.wait_event(free[i & 1])
+            return masks2[i & 1].data_ptr()
+
+        def post(i, t):
+            k = i & 1
+            done[k].record(s_pipe)
+            s_blob.wait_event(done[k])
+            ex.extract_device(masks2[k].data_ptr(), t * S, 100.0, stream=s_blob.cuda_stream)
+            free[k].record(s_blob)
+
+        run.pre, run.post = pre, post
         run.preroll(0.1, 32)
         elb = run.rounds(K, R)
+        s_blob.synchronize()
         sb = summarize_rounds(elb, K, S * T)
         res = [ex.result(i) for i in range(T * S)]
-        run.post = None
+        run.pre = run.post = None
         ok = [r for r in res if r is not None]
         out["detect_path"] = {
             "what": "steps 1-3 + GPU blob extraction (external contours, cv.contourArea >= 100, moments, "
-                    "bounding boxes, ordered contour points) on all %d masks of a step; only blob records "
-                    "and contour points are copied to the host" % (T * S),
+                    "bounding boxes, ordered contour points) on all %d masks of a step, on a second HIP stream "
+                    "beside the next step's kernels (double-buffered masks); only blob records and contour "
+                    "points are copied to the host" % (T * S),
             "value": sb["frames_per_s"], "unit_value": "frames/s", "ms_per_step": sb["ms_per_step"],
             "round_ms": sb["round_ms"],
             "blobs_per_mask": round(sum(len(r[0]) for r in ok) / max(1, len(ok)), 2),
