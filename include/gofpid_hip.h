@@ -200,6 +200,12 @@ int gof_pipeline_apply_host_many(gof_pipeline *p, const uint8_t *frames, uint8_t
                                  int n_frames);
 int gof_pipeline_apply_dev_many(gof_pipeline *p, const void *d_frames, void *d_masks, int n_frames,
                                 void *stream);
+/* Step 0 inside the pipeline (replaces cv.cvtColor(X, COLOR_BGR2GRAY | COLOR_RGB2GRAY) in
+ * front of it, pipeline.py:458-459): frames arrive with c_in (3 or 4) channels and are
+ * converted to grey on the device before step 1, with no round trip through the host.
+ * The pipeline must have been created with c == 1; every apply then takes
+ * streams x (h, w, c_in) frames.  c_in == 0 switches the conversion off again. */
+int gof_pipeline_set_convert(gof_pipeline *p, int c_in, int rgb_order);
 gof_mog2 *gof_pipeline_mog2(gof_pipeline *p);   /* NULL for an FD pipeline */
 /* mean number of Gaussian modes in use per pixel (m-bar of the byte model) */
 int gof_pipeline_mean_modes(gof_pipeline *p, double *mean_modes);

@@ -107,6 +107,7 @@ SIGNATURES = {
     "gof_pipeline_apply_host": (C.c_int, [C.c_void_p, _u8p, _u8p]),
     "gof_pipeline_apply_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gof_pipeline_mog2": (C.c_void_p, [C.c_void_p]),
+    "gof_pipeline_set_convert": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "gof_pipeline_mean_modes": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "gof_pipeline_apply_host_many": (C.c_int, [C.c_void_p, _u8p, _u8p, C.c_int]),
     "gof_pipeline_apply_dev_many": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,

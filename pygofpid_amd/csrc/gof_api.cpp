@@ -122,6 +122,9 @@ struct gof_pipeline {
     gof_mog2 *mog2 = nullptr;
     gof_fd *fd = nullptr;
     DevBuf in, out, blurred, m0, m1;
+    DevBuf gray;       // step 0 (gof_pipeline_set_convert): the converted frames
+    int cvt_c = 0;     // channels of the incoming frames when the conversion is on (else 0)
+    bool cvt_rgb = false;
     DevBuf rowflags;   // per launch chunk: [stream][h][tile column] bytes, see gofk::mog2_apply
     // fused blur + FD: the blurred last frame of the previous launch, one dword per
     // pixel (ping-pong), and which path this pipeline took on its first call
@@ -1215,6 +1218,7 @@ void gof_pipeline_destroy(gof_pipeline *p)
     p->blurred.release();
     p->m0.release();
     p->m1.release();
+    p->gray.release();
     p->rowflags.release();
     p->fd_prev[0].release();
     p->fd_prev[1].release();
@@ -1226,6 +1230,22 @@ void gof_pipeline_destroy(gof_pipeline *p)
 }
 
 gof_mog2 *gof_pipeline_mog2(gof_pipeline *p) { return p ? p->mog2 : nullptr; }
+
+int gof_pipeline_set_convert(gof_pipeline *p, int c_in, int rgb_order)
+{
+    if (!p)
+        return fail(GOF_EINVAL, "NULL argument");
+    if (c_in != 0 && (c_in != 3 && c_in != 4))
+        return fail(GOF_EINVAL, "conversion to grey takes 3- or 4-channel frames, got %d", c_in);
+    if (c_in != 0 && p->d.c != 1)
+        return fail(GOF_EINVAL, "a converting pipeline works on one channel; it was created with c = %d", p->d.c);
+    p->cvt_c = c_in;
+    p->cvt_rgb = rgb_order != 0;
+    return GOF_OK;
+}
+
+// channels of the frames an apply call is handed
+static int in_channels(const gof_pipeline *p) { return p->cvt_c ? p->cvt_c : p->d.c; }
 
 int gof_pipeline_apply_dev_many(gof_pipeline *p, const void *d_frames, void *d_masks, int n_frames,
                                 void *stream)
@@ -1243,8 +1263,15 @@ int gof_pipeline_apply_dev_many(gof_pipeline *p, const void *d_frames, void *d_m
         return fail(GOF_EINVAL, "n_frames * streams must not exceed 65535");
     int rc;
 
-    // step 1 (pipeline.py:462-467) -- unless it is fused into step 2
+    // step 0 (pipeline.py:458-459), when switched on: BGR / RGB -> grey, on the device
     const uint8_t *x = (const uint8_t *)d_frames;
+    if (p->cvt_c) {
+        if ((rc = p->gray.reserve((size_t)T * npx)))
+            return rc;
+        GOF_HIP(gofk::cvt_gray(x, (uint8_t *)p->gray.p, T * d.streams, d.h, d.w, p->cvt_c, p->cvt_rgb, s));
+        x = (const uint8_t *)p->gray.p;
+    }
+    // step 1 (pipeline.py:462-467) -- unless it is fused into step 2
     // FD: the fused kernel needs aligned frames.  The choice is made on the first
     // call and kept (the two paths keep the previous frame in different formats); a
     // later misaligned pointer is copied to an aligned buffer first.
@@ -1381,10 +1408,11 @@ int gof_pipeline_apply_host_many(gof_pipeline *p, const uint8_t *frames, uint8_t
     GOF_HIP(hipSetDevice(p->ctx->device));
     hipStream_t s = p->ctx->stream;
     const size_t npx = (size_t)n_frames * p->d.streams * p->d.h * p->d.w;
+    const size_t cin = (size_t)in_channels(p);
     int rc;
-    if ((rc = p->in.reserve(npx * p->d.c)) || (rc = p->out.reserve(npx)))
+    if ((rc = p->in.reserve(npx * cin)) || (rc = p->out.reserve(npx)))
         return rc;
-    GOF_HIP(hipMemcpyAsync(p->in.p, frames, npx * p->d.c, hipMemcpyHostToDevice, s));
+    GOF_HIP(hipMemcpyAsync(p->in.p, frames, npx * cin, hipMemcpyHostToDevice, s));
     if ((rc = gof_pipeline_apply_dev_many(p, p->in.p, p->out.p, n_frames, nullptr)))
         return rc;
     GOF_HIP(hipMemcpyAsync(masks, p->out.p, npx, hipMemcpyDeviceToHost, s));
@@ -1410,10 +1438,11 @@ int gof_pipeline_apply_host_blobs(gof_pipeline *p, const uint8_t *frames, int n_
     GOF_HIP(hipSetDevice(p->ctx->device));
     hipStream_t s = p->ctx->stream;
     const size_t npx = (size_t)n_frames * p->d.streams * p->d.h * p->d.w;
+    const size_t cin = (size_t)in_channels(p);
     int rc;
-    if ((rc = p->in.reserve(npx * p->d.c)) || (rc = p->out.reserve(npx)))
+    if ((rc = p->in.reserve(npx * cin)) || (rc = p->out.reserve(npx)))
         return rc;
-    GOF_HIP(hipMemcpyAsync(p->in.p, frames, npx * p->d.c, hipMemcpyHostToDevice, s));
+    GOF_HIP(hipMemcpyAsync(p->in.p, frames, npx * cin, hipMemcpyHostToDevice, s));
     if ((rc = gof_pipeline_apply_dev_many(p, p->in.p, p->out.p, n_frames, nullptr)))
         return rc;
     if ((rc = gof_blobs_extract_dev(b, p->out.p, n_frames * p->d.streams, min_area, nullptr)))

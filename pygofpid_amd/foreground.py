@@ -24,19 +24,26 @@ class ForegroundPipeline:
     detector : 'MOG2' | 'FD'
     morph : list of (op, kernel) with op in {'erode', 'dilate'} and kernel a
         (kh, kw) array (non-zero = member)
+    convert : None | 'BGR2GRAY' | 'RGB2GRAY' -- step 0 on the device [REF pipeline.py:458-459]:
+        frames arrive with shape's 3 or 4 channels, the detector works on their grey image
     """
 
     def __init__(self, shape, streams=1, blur=(3, 3, 4.0), detector="MOG2", fd_threshold=5,
                  morph=(("erode", np.ones((5, 5), np.uint8)), ("dilate", np.ones((5, 5), np.uint8))),
-                 mog2_params=None, device=None, ctx=None):
+                 mog2_params=None, device=None, ctx=None, convert=None):
         if len(shape) == 2:
             h, w, c = shape[0], shape[1], 1
         else:
             h, w, c = shape
+        # self.c: channels of the frames handed in; the detector sees 1 when converting
         self.h, self.w, self.c, self.streams = int(h), int(w), int(c), int(streams)
+        if convert not in (None, 'BGR2GRAY', 'RGB2GRAY'):
+            raise ValueError("convert must be None, 'BGR2GRAY' or 'RGB2GRAY'")
+        if convert and self.c not in (3, 4):
+            raise ValueError("conversion to grey takes 3- or 4-channel frames")
         lib = _lib.load()
         d = _lib.PipelineDesc()
-        d.streams, d.h, d.w, d.c = self.streams, self.h, self.w, self.c
+        d.streams, d.h, d.w, d.c = self.streams, self.h, self.w, (1 if convert else self.c)
         if blur is None:
             d.blur = _lib.BLUR_NONE
         elif blur[0] == 'box':
@@ -78,6 +85,9 @@ class ForegroundPipeline:
         self._h = C.c_void_p()
         _lib.check(lib.gof_pipeline_create(self._ctx.handle, C.byref(d), C.byref(self._h)))
         del keep  # the library copied the structuring elements
+        self.model_c = 1 if convert else self.c     # channels the detector (and its model) work on
+        if convert:
+            _lib.check(lib.gof_pipeline_set_convert(self._h, self.c, int(convert == 'RGB2GRAY')))
 
     # -- host buffers (what GOFPID.detect hands over) ------------------------
     def apply(self, frames):
@@ -207,7 +217,7 @@ class ForegroundPipeline:
         m = _lib.load().gof_pipeline_mog2(self._h)
         if not m:
             raise RuntimeError("not a MOG2 pipeline")
-        n, K, c = self.streams * self.h * self.w, self.nmixtures, self.c
+        n, K, c = self.streams * self.h * self.w, self.nmixtures, self.model_c
         wt, var = np.empty((K, n), np.float32), np.empty((K, n), np.float32)
         mean, modes = np.empty((K, c, n), np.float32), np.empty(n, np.uint8)
         f32 = C.POINTER(C.c_float)
@@ -220,15 +230,15 @@ class ForegroundPipeline:
         """Checkpoint the background model (the reference never serialises it, SURVEY.md
         section 5): an .npz of the SoA planes plus the frame counter and geometry."""
         st = self.mog2_state()
-        np.savez_compressed(path, geometry=np.array([self.streams, self.h, self.w, self.c]),
+        np.savez_compressed(path, geometry=np.array([self.streams, self.h, self.w, self.model_c]),
                             nmixtures=np.array(self.nmixtures), **st)
 
     def load_state(self, path):
         """Restore a checkpoint written by save_state() into this pipeline."""
         with np.load(path, allow_pickle=False) as z:
-            if z["geometry"].tolist() != [self.streams, self.h, self.w, self.c]:
+            if z["geometry"].tolist() != [self.streams, self.h, self.w, self.model_c]:
                 raise ValueError("checkpoint geometry %r does not match %r"
-                                 % (z["geometry"].tolist(), [self.streams, self.h, self.w, self.c]))
+                                 % (z["geometry"].tolist(), [self.streams, self.h, self.w, self.model_c]))
             m = _lib.load().gof_pipeline_mog2(self._h)
             if not m:
                 raise RuntimeError("not a MOG2 pipeline")
@@ -237,7 +247,7 @@ class ForegroundPipeline:
                 raise ValueError("checkpoint has nmixtures=%d, this pipeline %d"
                                  % (int(z["nmixtures"]), self.nmixtures))
             wt, var, mean, modes = _lib.mog2_state_arrays(
-                z, self.nmixtures, self.c, self.streams * self.h * self.w)
+                z, self.nmixtures, self.model_c, self.streams * self.h * self.w)
             _lib.check(_lib.load().gof_mog2_import(m, wt.ctypes.data_as(f32), var.ctypes.data_as(f32),
                                                    mean.ctypes.data_as(f32), _lib.p8(modes),
                                                    int(z["nframes"])))

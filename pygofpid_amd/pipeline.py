@@ -156,10 +156,7 @@ class GOFPID():
         elif X.shape != self.input_shape_:
             raise ValueError('Input shape has changed.')
 
-        if self.convert:
-            X = cv.cvtColor(X, self.convert)
-
-        # steps 1-3 on the GPU (and, fused, the contours / blob statistics of step 4)
+        # step 0 + steps 1-3 on the GPU (and, fused, the contours / blob statistics of step 4)
         self._foreground(X)
 
         # steps 4-7 on the host
@@ -219,12 +216,14 @@ class GOFPID():
         if not self._fused_checked:
             self._fused_checked = True
             args = self._fusable()
-            if args is not None:
+            conv = {cv.COLOR_BGR2GRAY: 'BGR2GRAY', cv.COLOR_RGB2GRAY: 'RGB2GRAY'}.get(self.convert) \
+                if self.convert else None
+            if args is not None and (not self.convert or (conv and X.ndim == 3 and X.shape[2] in (3, 4))):
                 shape = X.shape if X.ndim == 3 else (X.shape[0], X.shape[1], 1)
                 try:
                     self._fused = ForegroundPipeline(
                         shape, streams=1, blur=args[0], detector=args[1], morph=args[2],
-                        fd_threshold=getattr(self._frg_detect_mth, 'threshold', 5))
+                        fd_threshold=getattr(self._frg_detect_mth, 'threshold', 5), convert=conv)
                 except ValueError:
                     self._fused = None      # e.g. kernel larger than the fused path takes
         if self._fused is not None:
@@ -234,6 +233,8 @@ class GOFPID():
             self._mask_on_device = True
             return
         # generic path: the reference's own call sequence
+        if self.convert:
+            X = cv.cvtColor(X, self.convert)
         if self.blur:
             X = self.blur.get('fun')(X, self.blur.get('ksize'), self.blur.get('borderType'))
         mask = self._frg_detect_mth.apply(X)

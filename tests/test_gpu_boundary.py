@@ -176,3 +176,47 @@ def test_state_shape_validation(tmp_path):
         b_ = ForegroundPipeline((h, w, c), mog2_params=p3)
         np.savez(str(tmp_path / "bad.npz"), geometry=np.array([1, h, w, c]), nmixtures=np.array(3), **bad)
         b_.load_state(str(tmp_path / "bad.npz"))
+
+
+@pytest.mark.parametrize("code", ["BGR2GRAY", "RGB2GRAY"])
+@pytest.mark.parametrize("cin", [3, 4])
+def test_pipeline_fused_convert(oracle, code, cin):
+    """Step 0 inside the pipeline (gof_pipeline_set_convert, reference pipeline.py:458-459): colour
+    frames in, grey conversion on the device, then steps 1-3 -- masks and model equal the oracle's on
+    the oracle-converted frames; host, multi-frame and device-pointer entry points."""
+    import torch
+    from pygofpid_amd.foreground import ForegroundPipeline
+    h, w = 60, 88
+    clip = Clip(h, w, 3, seed=33, n_objects=2)
+    pipe = ForegroundPipeline((h, w, cin), convert=code)
+    ref = oracle.Pipeline(h, w, 1)
+    rng = np.random.default_rng(1)
+
+    def frame(t):
+        f = clip.frame(t)
+        if cin == 4:
+            f = np.concatenate([f, rng.integers(0, 256, (h, w, 1), dtype=np.uint8)], axis=2)
+        return f
+
+    def gray(f):
+        return oracle.cvt_gray(np.ascontiguousarray(f[:, :, :3]), rgb_order=(code == "RGB2GRAY"))
+
+    for t in range(4):
+        f = frame(t)
+        assert np.array_equal(pipe.apply(f), ref.apply(gray(f)))
+    fr = np.stack([frame(t) for t in range(4, 12)])
+    got = pipe.apply_many(fr)
+    for i in range(8):
+        assert np.array_equal(got[i], ref.apply(gray(fr[i])))
+    d = torch.from_numpy(frame(12)).cuda()
+    m = torch.empty((h, w), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    pipe.apply_device(d.data_ptr(), m.data_ptr())
+    pipe.synchronize()
+    assert np.array_equal(m.cpu().numpy(), ref.apply(gray(frame(12))))
+    st = pipe.mog2_state()
+    assert st["mean"].shape[1] == 1 and np.array_equal(st["modes"], ref.export()["modes"])
+    res = pipe.apply_blobs(frame(13), min_area=10.0)
+    assert np.array_equal(pipe.last_masks()[0, 0], ref.apply(gray(frame(13)))) and res[0] is not None
+    with pytest.raises(ValueError):
+        ForegroundPipeline((h, w, 1), convert=code)
