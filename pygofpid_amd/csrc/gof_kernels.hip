@@ -969,20 +969,27 @@ struct TapPatterns {
                            "+v"(win[2][2]));
 #pragma unroll
         for (int c = 0; c < C; c++) {
-            uint32_t acc = half;
-#pragma unroll
-            for (int j = 0; j < 3; j++) {
-                uint32_t h = __builtin_amdgcn_udot4(win[j][0], pat[c][0], 0u, false);
-                h = __builtin_amdgcn_udot4(win[j][1], pat[c][1], h, false);
-                h = __builtin_amdgcn_udot4(win[j][2], pat[c][2], h, false);
-                // acc += ky[j] * h as ONE v_mad_u32_u24 (h < 2^16, ky < 2^10).  The empty
-                // asm pins the running sum: without it the three products are
-                // re-associated into multiply, multiply-add, multiply, three-way add.
-                // (The multiply-add itself must stay compiler-generated: a VALU read of
-                // a v_dot4 result needs wait states that only the compiler inserts.)
-                acc = __umul24(ky[j], h) + acc;
-                asm volatile("" : "+v"(acc));
-            }
+            // The vertical taps of a Gaussian are symmetric (ky[0] == ky[2]; the launcher
+            // checks): rows 0 and 2 share one dot-product chain -- the accumulator carries
+            // h0 into h2 -- and one multiply-add, 2 v_mad_u32_u24 per channel instead of 3.
+            uint32_t h02 = __builtin_amdgcn_udot4(win[0][0], pat[c][0], 0u, false);
+            h02 = __builtin_amdgcn_udot4(win[0][1], pat[c][1], h02, false);
+            h02 = __builtin_amdgcn_udot4(win[0][2], pat[c][2], h02, false);
+            h02 = __builtin_amdgcn_udot4(win[2][0], pat[c][0], h02, false);
+            h02 = __builtin_amdgcn_udot4(win[2][1], pat[c][1], h02, false);
+            h02 = __builtin_amdgcn_udot4(win[2][2], pat[c][2], h02, false);
+            uint32_t h1 = __builtin_amdgcn_udot4(win[1][0], pat[c][0], 0u, false);
+            h1 = __builtin_amdgcn_udot4(win[1][1], pat[c][1], h1, false);
+            h1 = __builtin_amdgcn_udot4(win[1][2], pat[c][2], h1, false);
+            // acc += ky * h as ONE v_mad_u32_u24 each (h02 < 2^17, ky < 2^10).  The empty asm
+            // pins the running sum: without it the products are re-associated into
+            // multiply, multiply, add.  (The multiply-add itself must stay
+            // compiler-generated: a VALU read of a v_dot4 result needs wait states that
+            // only the compiler inserts.)
+            uint32_t acc = __umul24(ky[0], h02) + half;
+            asm volatile("" : "+v"(acc));
+            acc = __umul24(ky[1], h1) + acc;
+            asm volatile("" : "+v"(acc));
             out[c] = acc >> 16;
         }
     }
@@ -2118,7 +2125,7 @@ hipError_t mog2_apply(const uint8_t *frame, uint8_t *mask, const Mog2State &st, 
     const bool aln = fused_blur3 && ((size_t)w * c) % 4 == 0 && fstride % 4 == 0 &&
                      ((size_t)h * w * c) % 4 == 0 && (uintptr_t)frame % 4 == 0;
     // (its tap patterns add the outer taps where the border reflection folds them)
-    if (aln && T > 1 && w > 1 && t.kx[0] + t.kx[2] <= 255) {   // the multi-frame launch proper
+    if (aln && T > 1 && w > 1 && t.kx[0] + t.kx[2] <= 255 && t.ky[0] == t.ky[2]) {   // the multi-frame launch proper
         Mog2FramesArgs a;
         a.frame = frame;
         a.mask = mask;
@@ -2219,7 +2226,7 @@ bool fd_frames_supported(const uint8_t *frame, int n_img, int h, int w, int c, c
 {
     // byte taps whose folded outer pair fits a byte, at least two columns, and every
     // staged row of every frame at the same offset mod 4 (see mog2_apply)
-    return t.nkx == 3 && t.nky == 3 && t.box_scale == 0.0 && t.kx[0] < 256 && t.kx[1] < 256 &&
+    return t.nkx == 3 && t.nky == 3 && t.box_scale == 0.0 && t.ky[0] == t.ky[2] && t.kx[0] < 256 && t.kx[1] < 256 &&
            t.kx[2] < 256 && t.kx[0] + t.kx[2] <= 255 && w > 1 && ((size_t)w * c) % 4 == 0 &&
            ((size_t)h * w * c) % 4 == 0 && ((size_t)n_img * h * w * c) % 4 == 0 &&
            (uintptr_t)frame % 4 == 0 && (c == 1 || c == 3 || c == 4);
