@@ -1123,7 +1123,9 @@ __global__ __launch_bounds__(256, C <= 3 ? 7 : 1) void mog2_frames_kernel(const 
         kt.uni_ok = r[6];
         return kt;
     };
-    uint8_t *mp = a.mask + rowoff + xl;   // this pixel in the mask of the current frame
+    // this wave's row in the mask of the current frame: a wave-uniform base (scalar registers,
+    // advanced per frame on the scalar unit) + the lane's 32-bit offset
+    uint8_t *mrow = a.mask + rowoff;
 
     // Three frame loops, entered in this order and never re-entered: settled waves,
     // then waves whose pixels all have at most one mode, then the general update.
@@ -1145,8 +1147,8 @@ __global__ __launch_bounds__(256, C <= 3 ? 7 : 1) void mog2_frames_kernel(const 
             break;
         }
         if (valid)
-            *mp = 0;
-        mp += a.mask_stride;
+            mrow[xl] = 0;
+        mrow += a.mask_stride;
         rates = next;
         ti++;
     }
@@ -1160,8 +1162,8 @@ __global__ __launch_bounds__(256, C <= 3 ? 7 : 1) void mog2_frames_kernel(const 
         const uint8_t out = mog2_update_single<C>(M, nmodes, xin, kt);
         nz |= (__builtin_amdgcn_ballot_w64(out != 0) != 0 ? 1u : 0u) << ti;
         if (valid)
-            *mp = out;
-        mp += a.mask_stride;
+            mrow[xl] = out;
+        mrow += a.mask_stride;
         rates = next;
     }
     if (!multi_in && ti < T) {
@@ -1182,8 +1184,8 @@ __global__ __launch_bounds__(256, C <= 3 ? 7 : 1) void mog2_frames_kernel(const 
         const uint8_t out = mog2_update<C, kMaxModes>(M, nmodes, xin, kt);
         nz |= (__builtin_amdgcn_ballot_w64(out != 0) != 0 ? 1u : 0u) << ti;
         if (valid)
-            *mp = out;
-        mp += a.mask_stride;
+            mrow[xl] = out;
+        mrow += a.mask_stride;
         rates = next;
     }
     // one flag byte per wave and launch for the morphology that follows (the settled
