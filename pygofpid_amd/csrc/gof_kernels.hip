@@ -397,6 +397,83 @@ __device__ __forceinline__ uint8_t mog2_update_single(PixelModel<C> &M, int &nmo
     return out;
 }
 
+// One frame of a wave in which EVERY pixel's first mode fits (and the pixel is background):
+// what a wave on an object's trail sees once the object has passed -- background pixels that
+// still carry the object's and its shadow's modes for a few thousand frames.  mog2_update then
+// reduces, statement for statement, to: the fitted first mode's weight / mean / variance
+// update; the decay (and possible pruning, with the live loop bound) of the further modes;
+// the renormalisation.  No mode is opened, none is re-ordered (the fitted first mode only
+// grows, the others shrink together), no shadow test runs, every mask byte is 0.  Written as
+// a straight line with selects, slots beyond the wave's largest mode count skipped by
+// wave-uniform branches.  Returns false -- nothing changed -- if some pixel does not fit.
+template <int C>
+__device__ __forceinline__ bool mog2_try_first_fits(PixelModel<C> &M, int &nmodes_io, const float (&x)[C],
+                                                    const Mog2Consts &k)
+{
+    const float var = M.var[0];
+    float d[C];
+    float dist2;
+    if (C == 3) {
+        d[0] = M.mu[0][0] - x[0];
+        d[1] = M.mu[0][1] - x[1];
+        d[2] = M.mu[0][2] - x[2];
+        dist2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+    } else {
+        dist2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            d[c] = M.mu[0][c] - x[c];
+            dist2 += d[c] * d[c];
+        }
+    }
+    int nmodes = nmodes_io;
+    // every pixel: a first mode, which fits, and background (totalWeight = 0 < TB, dist2 < Tb var)
+    const bool ok = nmodes > 0 && dist2 < k.Tg * var && dist2 < k.Tb * var;
+    if (__float_as_int(k.TB) <= 0 || __builtin_amdgcn_ballot_w64(!ok) != 0)
+        return false;
+    const float negprune = -k.prune;
+    // m = 0, the fitted mode
+    float weight = k.alpha1 * M.w[0] + k.prune;
+    weight += k.alphaT;
+    const float kk = div_normal(k.alphaT, weight);
+#pragma unroll
+    for (int c = 0; c < C; c++)
+        M.mu[0][c] -= kk * d[c];
+    float varnew = var + kk * (dist2 - var);
+    varnew = varnew > k.var_min ? varnew : k.var_min;
+    varnew = varnew > k.var_max ? k.var_max : varnew;
+    M.var[0] = varnew;
+    bool pruned = weight < negprune;
+    float wstore = pruned ? 0.f : weight;
+    nmodes -= pruned ? 1 : 0;
+    M.w[0] = wstore;
+    float totalWeight = 0.f + wstore;
+    // m >= 1: decay, prune; the loop bound is the live mode count
+#pragma unroll
+    for (int m = 1; m < kMaxModes; m++) {
+        if (__builtin_amdgcn_ballot_w64(m < nmodes) == 0)
+            break;   // (no pixel of the wave has this slot; the later ones neither)
+        const bool live = m < nmodes;
+        const float wm = k.alpha1 * M.w[m] + k.prune;
+        pruned = live && wm < negprune;
+        wstore = pruned ? 0.f : wm;
+        nmodes -= pruned ? 1 : 0;
+        M.w[m] = live ? wstore : M.w[m];
+        totalWeight += live ? wstore : 0.f;
+    }
+    float inv = 0.f;
+    if (fabsf(totalWeight) > FLT_EPSILON)
+        inv = div_normal(1.f, totalWeight);
+#pragma unroll
+    for (int m = 0; m < kMaxModes; m++) {
+        if (m > 0 && __builtin_amdgcn_ballot_w64(m < nmodes) == 0)
+            break;
+        M.w[m] = m < nmodes ? M.w[m] * inv : M.w[m];
+    }
+    nmodes_io = nmodes;
+    return true;
+}
+
 // One frame of a SETTLED wave.  The caller guarantees that every pixel of the wave
 // has exactly one mode and that its weight is exactly 1.0f (where a fitted lone
 // mode renormalises to, frame after frame).  The weight arithmetic of
@@ -1181,7 +1258,10 @@ __global__ __launch_bounds__(256, C <= 3 ? 7 : 1) void mog2_frames_kernel(const 
         const Mog2Consts kt = frame_consts(rates);
         float xin[C];
         frame_input(xin, false);
-        const uint8_t out = mog2_update<C, kMaxModes>(M, nmodes, xin, kt);
+        // (waves on an object's trail, most frames: every first mode fits)
+        uint8_t out = 0;
+        if (!mog2_try_first_fits<C>(M, nmodes, xin, kt))
+            out = mog2_update<C, kMaxModes>(M, nmodes, xin, kt);
         nz |= (__builtin_amdgcn_ballot_w64(out != 0) != 0 ? 1u : 0u) << ti;
         if (valid)
             mrow[xl] = out;
