@@ -924,8 +924,10 @@ struct FrameTiles {
                         const unsigned d = lane + 64 * q < ndw ? lane + 64 * q : ndw - 1;
                         raw[ti][rr][q] = *(const uint32_t __attribute__((address_space(1))) *)(rowp[rr] + d * 4u);   // SGPR base + 32-bit lane offset
                     }
+#ifndef GOF_ABLATE_FRAME0   // (timing ablation: every frame of a launch reads frame 0's rows)
                     if (ti + 1 < NT)
                         rowp[rr] += frame_stride;
+#endif
                 }
             }
         } else {
