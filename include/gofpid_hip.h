@@ -47,7 +47,10 @@
 extern "C" {
 #endif
 
-#define GOF_ABI_VERSION 1
+/* 2: blob extraction (gof_blobs_*), gof_pipeline_set_convert, per-apply profile series; the
+ *    device layout behind gof_mog2_device_state / state_copy changed (a model buffer of
+ *    version 1 must not be copied into a version 2 library: re-export / import instead) */
+#define GOF_ABI_VERSION 2
 
 enum {
     GOF_OK = 0,
