@@ -205,3 +205,22 @@ def _detect_on_host_path(g, f):
     g._track_blob()
     g._post_filter()
     return g._maintain_alarm(g._detect_blob())
+
+
+def test_apply_blobs_frame_differencing_masks(oracle):
+    """FD pipelines leave {0, 84, 85} masks: any non-zero byte is foreground to findContours"""
+    from pygofpid_amd import blobs
+    from pygofpid_amd.foreground import ForegroundPipeline
+    h, w, c = 96, 160, 3
+    clip = Clip(h, w, c, seed=77, n_objects=3, speed=5)
+    pipe = ForegroundPipeline((h, w, c), detector="FD", fd_threshold=5)
+    ref = oracle.Pipeline(h, w, c, detector="FD", fd_thr=5.0)
+    seen = set()
+    for t in range(10):
+        f = clip.frame(t)
+        res = pipe.apply_blobs(f, min_area=4.0)[0]
+        mask = pipe.last_masks()[0, 0]
+        assert np.array_equal(mask, ref.apply(f))
+        seen |= set(np.unique(mask).tolist())
+        _same(res, blobs.host_result(mask, 4.0))
+    assert seen - {0}, "the clip produced no foreground at all"
