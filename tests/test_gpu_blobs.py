@@ -224,3 +224,26 @@ def test_apply_blobs_frame_differencing_masks(oracle):
         seen |= set(np.unique(mask).tolist())
         _same(res, blobs.host_result(mask, 4.0))
     assert seen - {0}, "the clip produced no foreground at all"
+
+
+@pytest.mark.parametrize("shape", [(270, 481), (2160, 3840)])
+def test_extract_batches_odd_and_4k(shape):
+    """batches of smoothed masks at an odd width (byte-wise loads everywhere) and at 4K"""
+    from pygofpid_amd import blobs
+    h, w = shape
+    n = 5 if h < 1000 else 2
+    rng = np.random.default_rng(h + w)
+    masks = np.zeros((n, h, w), np.uint8)
+    for i in range(n):
+        m = rng.random((h // 6 + 1, w // 6 + 1)) < (0.25 + 0.1 * i)
+        m = np.kron(m, np.ones((6, 6), bool))[:h, :w]                 # blocky blobs, touching diagonally
+        masks[i] = ndimage.binary_opening(m, np.ones((3, 3))).astype(np.uint8) * (255 if i % 2 else 127)
+    ex = blobs.BlobExtractor(n, h, w)
+    res = ex.extract(masks, 100.0)
+    for i in range(n):
+        want = blobs.host_result(masks[i], 100.0)
+        if len(want[0]) > 4096:
+            assert res[i] is None
+        else:
+            _same(res[i], want)
+    assert any(r is not None and len(r[0]) > 0 for r in res)
