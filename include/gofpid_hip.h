@@ -276,6 +276,10 @@ int gof_blobs_fetch(gof_blobs *b, int image, gof_blob_record *records, int max_r
  * image index = frame * streams + stream.  b must hold n_frames * streams images. */
 int gof_pipeline_apply_host_blobs(gof_pipeline *p, const uint8_t *frames, int n_frames,
                                   gof_blobs *b, double min_area);
+/* the same with the n_frames frames (each streams x (h, w, c)) in separate host buffers:
+ * no host-side gathering copy (a video reader hands out one array per frame) */
+int gof_pipeline_apply_host_blobs_ptrs(gof_pipeline *p, const uint8_t *const *frames, int n_frames,
+                                       gof_blobs *b, double min_area);
 int gof_pipeline_fetch_masks(gof_pipeline *p, uint8_t *masks, int n_frames);
 
 /* Per-kernel timing with HIP events on the launch stream (what bench.py's

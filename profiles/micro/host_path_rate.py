@@ -62,3 +62,9 @@ t0 = time.perf_counter(); n = 0
 while time.perf_counter() - t0 < 3:
     detect_host(gh, frames[n % 16]); n += 1
 print("GOFPID.detect with step 4 forced onto the host path (the r01 form):                  %.0f frames/s" % (n / (time.perf_counter() - t0)))
+gm = GOFPID().initialize()
+gm.detect_many(list(frames[:8]))
+t0 = time.perf_counter(); n = 0
+while time.perf_counter() - t0 < 3:
+    gm.detect_many(list(frames[(n % 2) * 8:(n % 2) * 8 + 8])); n += 8
+print("GOFPID.detect_many, 8 frames per call (one upload, 8-frame kernels, one download):   %.0f frames/s" % (n / (time.perf_counter() - t0)))

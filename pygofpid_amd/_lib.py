@@ -128,6 +128,8 @@ SIGNATURES = {
                                    C.POINTER(C.c_int)]),
     "gof_blobs_fetch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "gof_pipeline_apply_host_blobs": (C.c_int, [C.c_void_p, _u8p, C.c_int, C.c_void_p, C.c_double]),
+    "gof_pipeline_apply_host_blobs_ptrs": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_void_p,
+                                                     C.c_double]),
     "gof_pipeline_fetch_masks": (C.c_int, [C.c_void_p, _u8p, C.c_int]),
     "gof_pipeline_profile_enable": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "gof_pipeline_profile_stride": (C.c_int, [C.c_void_p, C.c_int]),

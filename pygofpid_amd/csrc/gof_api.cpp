@@ -1452,6 +1452,37 @@ int gof_pipeline_apply_host_blobs(gof_pipeline *p, const uint8_t *frames, int n_
     return GOF_OK;
 }
 
+int gof_pipeline_apply_host_blobs_ptrs(gof_pipeline *p, const uint8_t *const *frames, int n_frames,
+                                       gof_blobs *b, double min_area)
+{
+    if (!p || !frames || !b)
+        return fail(GOF_EINVAL, "NULL argument");
+    if (n_frames < 1 || n_frames > 4096)
+        return fail(GOF_EINVAL, "n_frames must be in [1, 4096], got %d", n_frames);
+    if (b->ctx != p->ctx || b->h != p->d.h || b->w != p->d.w || b->n_img < n_frames * p->d.streams)
+        return fail(GOF_EINVAL, "blob scratch (%d images of %dx%d) does not fit %d frames of %d streams of %dx%d",
+                    b->n_img, b->h, b->w, n_frames, p->d.streams, p->d.h, p->d.w);
+    for (int i = 0; i < n_frames; i++)
+        if (!frames[i])
+            return fail(GOF_EINVAL, "frames[%d] is NULL", i);
+    GOF_HIP(hipSetDevice(p->ctx->device));
+    hipStream_t s = p->ctx->stream;
+    const size_t per = (size_t)p->d.streams * p->d.h * p->d.w, cin = (size_t)in_channels(p);
+    int rc;
+    if ((rc = p->in.reserve((size_t)n_frames * per * cin)) || (rc = p->out.reserve((size_t)n_frames * per)))
+        return rc;
+    for (int i = 0; i < n_frames; i++)
+        GOF_HIP(hipMemcpyAsync((uint8_t *)p->in.p + (size_t)i * per * cin, frames[i], per * cin,
+                               hipMemcpyHostToDevice, s));
+    if ((rc = gof_pipeline_apply_dev_many(p, p->in.p, p->out.p, n_frames, nullptr)))
+        return rc;
+    if ((rc = gof_blobs_extract_dev(b, p->out.p, n_frames * p->d.streams, min_area, nullptr)))
+        return rc;
+    GOF_HIP(hipStreamSynchronize(s));
+    b->pending = false;
+    return GOF_OK;
+}
+
 int gof_pipeline_fetch_masks(gof_pipeline *p, uint8_t *masks, int n_frames)
 {
     if (!p || !masks || n_frames < 1)

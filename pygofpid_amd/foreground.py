@@ -139,6 +139,23 @@ class ForegroundPipeline:
         self._last_T = T
         return [self._blobs.result(i) for i in range(T * self.streams)]
 
+    def apply_blobs_frames(self, frames, min_area=100.0):
+        """apply_blobs() for a LIST of frames (each what apply() takes), uploaded straight from
+        their own buffers -- no gathering copy on the host.  Returns the same list of results."""
+        from .blobs import BlobExtractor
+        arrs = [_lib.as_u8(f, "frames") for f in frames]
+        per = self.streams * self.h * self.w * self.c
+        if not arrs or any(a.size != per for a in arrs):
+            raise ValueError("Input shape has changed.")
+        T = len(arrs)
+        if getattr(self, "_blobs", None) is None or self._blobs.n_images < T * self.streams:
+            self._blobs = BlobExtractor(T * self.streams, self.h, self.w, ctx=self._ctx)
+        ptrs = (C.c_void_p * T)(*[a.ctypes.data for a in arrs])
+        _lib.check(_lib.load().gof_pipeline_apply_host_blobs_ptrs(self._h, ptrs, T, self._blobs.handle,
+                                                                  float(min_area)))
+        self._last_T = T
+        return [self._blobs.result(i) for i in range(T * self.streams)]
+
     def last_masks(self):
         """The masks of the last apply_blobs() call, downloaded now: (T, streams, h, w)."""
         T = getattr(self, "_last_T", 0)

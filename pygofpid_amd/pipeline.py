@@ -2,7 +2,7 @@
 
 Drop-in for `pygofpid.pipeline.GOFPID` (reference pygofpid/pipeline.py:22-853):
 same constructor arguments and defaults, `initialize()`, `detect(X) -> bool`,
-`display(X, display)`, and the attributes `foreground_mask_`, `blobs_`,
+`display(X, display)` (plus `detect_many(frames)`, the batch form), and the attributes `foreground_mask_`, `blobs_`,
 `tracked_blobs_`, `input_shape_`.
 
 What runs where
@@ -115,6 +115,7 @@ class GOFPID():
         self._fused_checked = False
         self._mask = None           # host copy of the final mask (lazy on the fused path)
         self._mask_on_device = False
+        self._mask_index = 0        # which mask of the last fused call is the current frame's
         self._gpu_blobs = None      # (records, points) of the last frame, or None
         return self
 
@@ -165,6 +166,41 @@ class GOFPID():
         self._post_filter()
         return self._maintain_alarm(self._detect_blob())
 
+    def detect_many(self, frames):
+        """detect() on consecutive frames of the stream, in order: a list of its return values.
+
+        Not in the reference; same results as calling detect() frame by frame (steps 4-7 never
+        feed back into steps 1-3).  On the fused path all frames go through ONE upload and the
+        multi-frame kernels (the background model crosses HBM once per 8 frames) and all their
+        blob records come back in one download; the host steps then run frame by frame.
+        Attributes (`blobs_`, `tracked_blobs_`, `foreground_mask_`) are those of the last frame.
+        """
+        frames = [np.asarray(f) for f in frames]
+        out = []
+        if frames and not getattr(self, '_fused_checked', False):
+            out.append(self.detect(frames[0]))        # decides the path, calibrates on the shape
+            frames = frames[1:]
+        if self._fused is None or not frames:
+            return out + [self.detect(f) for f in frames]
+        for f in frames:
+            if f.shape != self.input_shape_:
+                raise ValueError('Input shape has changed.')
+        results = self._fused.apply_blobs_frames(frames, min_area=self._AREA_MIN)
+        masks = None
+        for i, res in enumerate(results):
+            self._gpu_blobs = res
+            self._mask = None
+            self._mask_on_device = True
+            self._mask_index = i
+            if res is None:                           # device scratch overflow: this frame's mask, host path
+                masks = self._fused.last_masks() if masks is None else masks
+                self._mask = masks[i, 0]
+            self._find_blob()
+            self._track_blob()
+            self._post_filter()
+            out.append(self._maintain_alarm(self._detect_blob()))
+        return out
+
     def _fusable(self):
         """(blur, detector, morph) arguments of a ForegroundPipeline, or None when
         the configuration contains callables that are not this package's."""
@@ -201,7 +237,7 @@ class GOFPID():
         """The final mask of the last frame.  On the fused path it lives on the device
         and is downloaded when (and only when) it is read."""
         if self._mask is None and self._mask_on_device:
-            self._mask = self._fused.last_masks()[0, 0]
+            self._mask = self._fused.last_masks()[self._mask_index, 0]
         if self._mask is None:
             raise AttributeError("foreground_mask_")
         return self._mask
@@ -231,6 +267,7 @@ class GOFPID():
             self._gpu_blobs = self._fused.apply_blobs(X, min_area=self._AREA_MIN)[0]
             self._mask = None
             self._mask_on_device = True
+            self._mask_index = 0
             return
         # generic path: the reference's own call sequence
         if self.convert:

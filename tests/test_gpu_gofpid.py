@@ -211,3 +211,25 @@ def test_ilids_view_configs_masks_bit_exact(oracle):
             assert gofpid.detect(f) in (True, False)
             assert np.array_equal(gofpid.foreground_mask_, ref.apply(f))
         assert gofpid.post_filter['perimeter'].dtype == np.int32      # calibrated to pixels
+
+
+def test_gofpid_detect_many_equals_detect(G):
+    """detect_many (one upload, multi-frame kernels, one download of all blob records) gives
+    what frame-by-frame detect() gives: return values, blobs, tracks, masks"""
+    h, w = 180, 320
+    clip = Clip(h, w, 3, seed=29, n_objects=3)
+    a = G(post_filter=post_filter.copy()).initialize()
+    b = G(post_filter=post_filter.copy()).initialize()
+    want = [a.detect(clip.frame(t)) for t in range(27)]
+    got = []
+    for t0, n in ((0, 1), (1, 8), (9, 8), (17, 3), (20, 7)):
+        got += b.detect_many([clip.frame(t) for t in range(t0, t0 + n)])
+    assert got == want
+    assert len(a.tracked_blobs_) == len(b.tracked_blobs_) and len(a.blobs_) == len(b.blobs_)
+    for x, y in zip(a.blobs_, b.blobs_):
+        assert np.array_equal(x['contour'], y['contour']) and np.array_equal(x['center'], y['center'])
+    for x, y in zip(a.tracked_blobs_, b.tracked_blobs_):
+        assert x['presence'] == y['presence'] and x['filtered'] == y['filtered']
+    assert np.array_equal(a.foreground_mask_, b.foreground_mask_)
+    with pytest.raises(ValueError):
+        b.detect_many([clip.frame(0)[:-1]])
