@@ -247,3 +247,20 @@ def test_extract_batches_odd_and_4k(shape):
         else:
             _same(res[i], want)
     assert any(r is not None and len(r[0]) > 0 for r in res)
+
+
+def test_reference_pins_through_the_device_path():
+    """reference tests/test_helpers.py:59-80 on the device: find_contours on its random 0/1 mask runs
+    (and equals the host follower); the square's bottom / center are (5, 10) / (5, 5)"""
+    from pygofpid_amd import blobs
+    np.random.seed(17)
+    mask = np.random.randint(low=0, high=2, size=(64, 64), dtype=np.uint8)
+    ex = blobs.BlobExtractor(1, 64, 64, crack_capacity=2 * 64 * 64 + 16)
+    _same(ex.extract(mask, 0.0)[0], blobs.host_result(mask, 0.0))
+    sq = np.zeros((64, 64), np.uint8)
+    sq[0:11, 0:11] = 1
+    recs, pts = ex.extract(sq, 100.0)[0]
+    assert len(recs) == 1 and recs[0]["n_points"] == 40
+    for dtype in (np.int16, np.uint16, np.int32, np.uint32):
+        bottom, center = blobs.bottom_and_center(recs[0], dtype=dtype)
+        assert bottom.tolist() == [5, 10] and center.tolist() == [5, 5]

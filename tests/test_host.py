@@ -203,3 +203,21 @@ def test_gofpid_alarmdef_errors_and_headless():
         GOFPID(alarm_def={'keep_alarm': True}).initialize()
     with pytest.raises(NotImplementedError):
         GOFPID(post_filter=dict(post_filter, display_config=True)).initialize()
+
+
+@pytest.mark.parametrize("dtype", [np.int16, np.uint16, np.int32, np.uint32])
+def test_blob_records_reproduce_reference_pins(dtype):
+    """The reference's own value pins for step 4's geometry (tests/test_helpers.py:65-80: the square
+    contour [[0,0],[0,10],[10,10],[10,0]] has bottom (5, 10) and center (5, 5)), through the record
+    arithmetic the GPU path uses (blobs.moments_of / bottom_and_center on exact shoelace sums)."""
+    from pygofpid_amd import blobs
+    from pygofpid_amd.helpers import get_bottom, get_center
+    contour = np.array([[0, 0], [0, 10], [10, 10], [10, 0]], dtype=np.int32)
+    assert get_bottom(contour, dtype=dtype).tolist() == [5, 10] and get_center(contour, dtype=dtype).tolist() == [5, 5]
+    mask = np.zeros((16, 20), np.uint8)
+    mask[0:11, 0:11] = 255                       # its border pixels trace that square (40 points)
+    recs, pts = blobs.host_result(mask, 100.0)
+    assert len(recs) == 1 and recs[0]["n_points"] == 40 and abs(recs[0]["a00"]) == 200
+    bottom, center = blobs.bottom_and_center(recs[0], dtype=dtype)
+    assert bottom.dtype == dtype and bottom.tolist() == [5, 10] and center.tolist() == [5, 5]
+    assert blobs.moments_of(recs[0]) == hostcv.moments(pts.reshape(-1, 1, 2))
