@@ -105,6 +105,11 @@ hipError_t mog2_apply(const uint8_t *frame, uint8_t *mask, const Mog2State &st, 
                       int w, int c, int T, const Mog2Consts &k, bool fused_blur3, const Taps &t,
                       hipStream_t s, uint8_t *rowflags, bool *rowflags_written, size_t frame_bytes);
 
+// the multi-frame launch behind mog2_apply (gof_mog2_frames.hip); mog2_apply decides when it applies
+hipError_t mog2_frames_launch(const uint8_t *frame, uint8_t *mask, const Mog2State &st, int n_img, int h,
+                              int w, int c, int T, const Mog2Consts &k, const Taps &t, hipStream_t s,
+                              uint8_t *rowflags);
+
 hipError_t fd_apply(const uint8_t *cur, const uint8_t *prev, bool has_prev, int ithr,
                     uint8_t *mask, int n_img, int h, int w, int c, hipStream_t s);
 

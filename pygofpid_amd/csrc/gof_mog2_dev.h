@@ -1,0 +1,722 @@
+// Device-side pieces the MOG2 kernels share (gof_mog2.hip: per-frame kernel and launcher,
+// gof_mog2_frames.hip: the multi-frame launch) and the staging / tap-pattern front end that
+// fd_frames_kernel (gof_kernels.hip) borrows.  Internal; everything here has internal linkage.
+#pragma once
+#include "gof_kernels.h"
+
+#include <float.h>
+#include <stdlib.h>
+
+namespace gofk {
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// MOG2 (+ optional fused 3x3 fixed-point blur)
+// ---------------------------------------------------------------------------
+// Reference call sites: cv.GaussianBlur at pipeline.py:463-467 and
+// cv.createBackgroundSubtractorMOG2().apply at pipeline.py:232/470; the
+// arithmetic is cv2's, restated in oracle/gof_oracle.c.
+//
+// Tile = 64 px x 4 rows, one wave per row, one pixel per lane: every model
+// plane access of a wave is one 256-B contiguous segment.
+
+constexpr int TW = 64;
+constexpr int TH = 4;
+// the byte of the mode-count plane: count in the low bits, kW0One = "the first mode's
+// weight is exactly 1.0f" (kept true by every kernel that writes the byte; a byte
+// without the bit only costs a read of the weight plane)
+constexpr int kModeCount = 0x7f, kW0One = 0x80;
+
+template <int C>
+struct PixelModel {
+    float w[kMaxModes];
+    float var[kMaxModes];
+    float mu[kMaxModes][C];
+};
+
+template <int C>
+__device__ __forceinline__ void swap_modes(PixelModel<C> &M, int i, bool doit)
+{
+    // i is a compile-time constant after unrolling: registers, not scratch
+    float a = M.w[i], b = M.w[i - 1];
+    M.w[i] = doit ? b : a;
+    M.w[i - 1] = doit ? a : b;
+    a = M.var[i];
+    b = M.var[i - 1];
+    M.var[i] = doit ? b : a;
+    M.var[i - 1] = doit ? a : b;
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+        a = M.mu[i][c];
+        b = M.mu[i - 1][c];
+        M.mu[i][c] = doit ? b : a;
+        M.mu[i - 1][c] = doit ? a : b;
+    }
+}
+
+// Model layout in HBM (gof_kernels.h, Mog2State): per mode a weight plane and a VECTOR
+// plane that holds {variance, mean[0..]} of a pixel side by side -- float4 for BGR, so the
+// 16 bytes a settled pixel updates per frame are ONE global_load_dwordx4 / store_dwordx4
+// per lane (1 KiB per wave-instruction) instead of four dword streams; float2 for grey;
+// float4 + a fifth plane for 4-channel frames.  `mode` = first float of the mode's planes,
+// `pix` = pixel index (wave-uniform row offset + lane).
+template <int C>
+__device__ __forceinline__ void load_mode_vec(const float *mode, size_t np, size_t pix, float &var,
+                                              float (&mu)[C])
+{
+    if (C == 1) {
+        const float2 q = ((const float2 *)(mode + np))[pix];
+        var = q.x;
+        mu[0] = q.y;
+    } else {
+        const float4 q = ((const float4 *)(mode + np))[pix];
+        var = q.x;
+        mu[0] = q.y;
+        mu[1 % C] = q.z;
+        mu[2 % C] = q.w;
+        if (C == 4)
+            mu[3 % C] = (mode + 5 * np)[pix];
+    }
+}
+
+template <int C>
+__device__ __forceinline__ void store_mode_vec(float *mode, size_t np, size_t pix, float var,
+                                               const float (&mu)[C])
+{
+    if (C == 1) {
+        ((float2 *)(mode + np))[pix] = make_float2(var, mu[0]);
+    } else {
+        ((float4 *)(mode + np))[pix] = make_float4(var, mu[0], mu[1 % C], mu[2 % C]);
+        if (C == 4)
+            (mode + 5 * np)[pix] = mu[3 % C];
+    }
+}
+
+// IEEE-correct a / b for operands in the normal range with a normal quotient:
+// the Newton / residual chain hipcc itself emits for a float division, without
+// its range scaling (v_div_scale, v_div_fmas' scale) and special-case fix-up
+// (v_div_fixup), which are no-ops there.  8 instructions instead of 11; used
+// where the denominator is a mixture weight (1e-4 .. 2) or a weight sum.
+__device__ __forceinline__ float div_normal(float a, float b)
+{
+    const float r0 = __builtin_amdgcn_rcpf(b);
+    const float nb = -b;
+    const float e0 = __builtin_fmaf(nb, r0, 1.0f);
+    const float r1 = __builtin_fmaf(e0, r0, r0);
+    const float q0 = a * r1;
+    const float e1 = __builtin_fmaf(nb, q0, a);
+    const float q1 = __builtin_fmaf(e1, r1, q0);
+    const float e2 = __builtin_fmaf(nb, q1, a);
+    return __builtin_fmaf(e2, r1, q1);
+}
+
+// detectShadowGMM [OPENCV-RECALL] over the first LIM slots, on the model AFTER
+// this frame's update.  Returns true for a shadow pixel.
+template <int C, int LIM>
+__device__ __forceinline__ bool shadow_test(const PixelModel<C> &M, int nmodes, const float (&x)[C],
+                                            const Mog2Consts &k)
+{
+    bool shadow = false;
+    if (k.detect_shadows) {
+        float tW = 0.f;
+        bool done = false;
+#pragma unroll
+        for (int m = 0; m < LIM; m++) {
+            if (!done && m < nmodes) {
+                float num = 0.f, den = 0.f;
+#pragma unroll
+                for (int c = 0; c < C; c++) {
+                    num += x[c] * M.mu[m][c];
+                    den += M.mu[m][c] * M.mu[m][c];
+                }
+                if (den == 0.f) {
+                    done = true;
+                } else {
+                    if (num <= den && num >= k.tau * den) {
+                        float a = num / den;
+                        float dist2a = 0.f;
+#pragma unroll
+                        for (int c = 0; c < C; c++) {
+                            float dD = a * M.mu[m][c] - x[c];
+                            dist2a += dD * dD;
+                        }
+                        if (dist2a < k.Tb * M.var[m] * a * a) {
+                            shadow = true;
+                            done = true;
+                        }
+                    }
+                    if (!done) {
+                        tW += M.w[m];
+                        if (tW > k.TB)
+                            done = true;
+                    }
+                }
+            }
+        }
+    }
+    return shadow;
+}
+
+// One pixel of MOG2Invoker::operator() on a register-resident model.
+// Statement order follows oracle/gof_oracle.c mog2_pixel(); the only
+// re-statement is that the fitted mode's new weight is stored in its slot
+// BEFORE it is bubbled up, so that it travels with the swaps (OpenCV swaps
+// first and then writes gmm[mode - swap_count].weight: same end state).
+//
+// MAXIN is a compile-time upper bound of the mode count on entry.  The kernel
+// calls the MAXIN = 1 instance when no pixel of the wave has a second mode
+// (four waves out of five on surveillance footage): same statements, same
+// order, same results, but only the slots that can be live (0 on entry, 0..1 on
+// exit) are ever touched, which removes most of the unrolled predication.
+template <int C, int MAXIN>
+__device__ __forceinline__ uint8_t mog2_update(PixelModel<C> &M, int &nmodes_io, const float (&x)[C],
+                                               const Mog2Consts &k)
+{
+    constexpr int LIN = MAXIN < kMaxModes ? MAXIN : kMaxModes;            // live slots on entry
+    constexpr int LOUT = MAXIN + 1 < kMaxModes ? MAXIN + 1 : kMaxModes;   // ... after an insertion
+    int nmodes = nmodes_io;
+    bool background = false, fits = false;
+    float totalWeight = 0.f;
+    const float negprune = -k.prune;
+
+#pragma unroll
+    for (int m = 0; m < LIN; m++) {
+        if (m < nmodes) {  // live bound: nmodes shrinks when a mode is pruned
+            float weight = k.alpha1 * M.w[m] + k.prune;
+            bool fit_here = false;
+            if (!fits) {
+                float var = M.var[m];
+                float d[C];
+                float dist2;
+                if (C == 3) {
+                    d[0] = M.mu[m][0] - x[0];
+                    d[1] = M.mu[m][1] - x[1];
+                    d[2] = M.mu[m][2] - x[2];
+                    dist2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+                } else {
+                    dist2 = 0.f;
+#pragma unroll
+                    for (int c = 0; c < C; c++) {
+                        d[c] = M.mu[m][c] - x[c];
+                        dist2 += d[c] * d[c];
+                    }
+                }
+                if (totalWeight < k.TB && dist2 < k.Tb * var)
+                    background = true;
+                if (dist2 < k.Tg * var) {
+                    fits = true;
+                    fit_here = true;
+                    weight += k.alphaT;
+                    float kk = div_normal(k.alphaT, weight);   // weight >= 0.95 alphaT: normal range
+#pragma unroll
+                    for (int c = 0; c < C; c++)
+                        M.mu[m][c] -= kk * d[c];
+                    float varnew = var + kk * (dist2 - var);
+                    varnew = varnew > k.var_min ? varnew : k.var_min;
+                    varnew = varnew > k.var_max ? k.var_max : varnew;
+                    M.var[m] = varnew;
+                }
+            }
+            float wstore = weight;
+            if (weight < negprune) {
+                wstore = 0.f;
+                nmodes--;
+            }
+            M.w[m] = wstore;
+            totalWeight += wstore;
+            if (fit_here) {
+                bool go = true;
+#pragma unroll
+                for (int i = m; i > 0; i--) {
+                    go = go && !(weight < M.w[i - 1]);
+                    swap_modes<C>(M, i, go);
+                }
+            }
+        }
+    }
+
+    float inv = 0.f;
+    if (fabsf(totalWeight) > FLT_EPSILON)
+        inv = div_normal(1.f, totalWeight);
+#pragma unroll
+    for (int m = 0; m < LIN; m++)
+        if (m < nmodes)
+            M.w[m] *= inv;
+
+    if (!fits && k.alphaT > 0.f) {
+        int slot = nmodes == k.nmix ? k.nmix - 1 : nmodes++;
+        bool first = nmodes == 1;
+#pragma unroll
+        for (int m = 0; m < LOUT; m++) {
+            if (m == slot) {
+                M.w[m] = first ? 1.f : k.alphaT;
+                M.var[m] = k.var_init;
+#pragma unroll
+                for (int c = 0; c < C; c++)
+                    M.mu[m][c] = x[c];
+            } else if (!first && m < nmodes - 1) {
+                M.w[m] *= k.alpha1;
+            }
+        }
+        bool go = true;
+#pragma unroll
+        for (int i = LOUT - 1; i > 0; i--) {
+            bool in = i <= nmodes - 1;
+            bool sw = in && go && !(k.alphaT < M.w[i - 1]);
+            if (in)
+                go = sw;
+            swap_modes<C>(M, i, sw);
+        }
+    }
+    nmodes_io = nmodes;
+
+    if (background)
+        return 0;
+    return shadow_test<C, LOUT>(M, nmodes, x, k) ? (uint8_t)k.shadow_value : (uint8_t)255;
+}
+
+// The MAXIN = 1 instance of mog2_update written without per-lane branches on the
+// common path.  Same statements on the same values (every lane evaluates the fit
+// arithmetic, selects keep it only where the reference would have executed it);
+// the rare parts -- inserting a new mode, the shadow test of a non-background
+// pixel -- sit behind wave-uniform branches.  On a wave of pure background this
+// is a straight line of ~70 vector instructions and no exec-mask bookkeeping,
+// which matters because the multi-frame kernel is bound by VALU + SALU issue.
+template <int C>
+__device__ __forceinline__ uint8_t mog2_update_single(PixelModel<C> &M, int &nmodes_io,
+                                                      const float (&x)[C], const Mog2Consts &k)
+{
+    int nmodes = nmodes_io;               // 0 or 1 on entry
+    const bool has = nmodes > 0;
+    const float var = M.var[0];
+    float d[C];
+    float dist2;
+    if (C == 3) {
+        d[0] = M.mu[0][0] - x[0];
+        d[1] = M.mu[0][1] - x[1];
+        d[2] = M.mu[0][2] - x[2];
+        dist2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+    } else {
+        dist2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            d[c] = M.mu[0][c] - x[c];
+            dist2 += d[c] * d[c];
+        }
+    }
+    // mean / variance of a fitted mode 0 (kk = alphaT / weight)
+    auto fit_update = [&](bool fit, float kk) {
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const float mnew = M.mu[0][c] - kk * d[c];
+            M.mu[0][c] = fit ? mnew : M.mu[0][c];
+        }
+        float varnew = var + kk * (dist2 - var);
+        varnew = varnew > k.var_min ? varnew : k.var_min;
+        varnew = varnew > k.var_max ? k.var_max : varnew;
+        M.var[0] = fit ? varnew : var;
+    };
+    bool background, fit;
+    {
+        const float weight = k.alpha1 * M.w[0] + k.prune;
+        background = has && 0.f < k.TB && dist2 < k.Tb * var;
+        fit = has && dist2 < k.Tg * var;
+        const float wfit = weight + k.alphaT;
+        const float kk = div_normal(k.alphaT, wfit);
+        fit_update(fit, kk);
+        const float w2 = fit ? wfit : weight;
+        const bool pruned = has && w2 < -k.prune;
+        const float wstore = pruned ? 0.f : w2;
+        nmodes -= pruned ? 1 : 0;
+        const float total = has ? 0.f + wstore : 0.f;
+        float inv = 0.f;
+        if (fabsf(total) > FLT_EPSILON)
+            inv = div_normal(1.f, total);
+        {
+            const float wn = nmodes > 0 ? wstore * inv : wstore;
+            M.w[0] = has ? wn : M.w[0];
+        }
+    }
+
+    const bool need = !fit && k.alphaT > 0.f;
+    if (__builtin_amdgcn_ballot_w64(need) != 0) {   // wave-uniform: some pixel opens a new mode
+        if (need) {
+            const int slot = nmodes == k.nmix ? k.nmix - 1 : nmodes++;
+            const bool first = nmodes == 1;
+#pragma unroll
+            for (int m = 0; m < 2; m++) {
+                if (m == slot) {
+                    M.w[m] = first ? 1.f : k.alphaT;
+                    M.var[m] = k.var_init;
+#pragma unroll
+                    for (int c = 0; c < C; c++)
+                        M.mu[m][c] = x[c];
+                } else if (!first && m < nmodes - 1) {
+                    M.w[m] *= k.alpha1;
+                }
+            }
+            const bool sw = 1 <= nmodes - 1 && !(k.alphaT < M.w[0]);
+            swap_modes<C>(M, 1, sw);
+        }
+    }
+    nmodes_io = nmodes;
+
+    uint8_t out = 0;
+    if (__builtin_amdgcn_ballot_w64(!background) != 0) {   // wave-uniform: some pixel is not background
+        if (!background)
+            out = shadow_test<C, 2>(M, nmodes, x, k) ? (uint8_t)k.shadow_value : (uint8_t)255;
+    }
+    return out;
+}
+
+// One frame of a wave in which EVERY pixel's first mode fits (and the pixel is background):
+// what a wave on an object's trail sees once the object has passed -- background pixels that
+// still carry the object's and its shadow's modes for a few thousand frames.  mog2_update then
+// reduces, statement for statement, to: the fitted first mode's weight / mean / variance
+// update; the decay (and possible pruning, with the live loop bound) of the further modes;
+// the renormalisation.  No mode is opened, none is re-ordered (the fitted first mode only
+// grows, the others shrink together), no shadow test runs, every mask byte is 0.  Written as
+// a straight line with selects, slots beyond the wave's largest mode count skipped by
+// wave-uniform branches.  Returns false -- nothing changed -- if some pixel does not fit.
+template <int C>
+__device__ __forceinline__ bool mog2_try_first_fits(PixelModel<C> &M, int &nmodes_io, const float (&x)[C],
+                                                    const Mog2Consts &k)
+{
+    const float var = M.var[0];
+    float d[C];
+    float dist2;
+    if (C == 3) {
+        d[0] = M.mu[0][0] - x[0];
+        d[1] = M.mu[0][1] - x[1];
+        d[2] = M.mu[0][2] - x[2];
+        dist2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+    } else {
+        dist2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            d[c] = M.mu[0][c] - x[c];
+            dist2 += d[c] * d[c];
+        }
+    }
+    int nmodes = nmodes_io;
+    // every pixel: a first mode, which fits, and background (totalWeight = 0 < TB, dist2 < Tb var)
+    const bool ok = nmodes > 0 && dist2 < k.Tg * var && dist2 < k.Tb * var;
+    if (__float_as_int(k.TB) <= 0 || __builtin_amdgcn_ballot_w64(!ok) != 0)
+        return false;
+    const float negprune = -k.prune;
+    // m = 0, the fitted mode
+    float weight = k.alpha1 * M.w[0] + k.prune;
+    weight += k.alphaT;
+    const float kk = div_normal(k.alphaT, weight);
+#pragma unroll
+    for (int c = 0; c < C; c++)
+        M.mu[0][c] -= kk * d[c];
+    float varnew = var + kk * (dist2 - var);
+    varnew = varnew > k.var_min ? varnew : k.var_min;
+    varnew = varnew > k.var_max ? k.var_max : varnew;
+    M.var[0] = varnew;
+    bool pruned = weight < negprune;
+    float wstore = pruned ? 0.f : weight;
+    nmodes -= pruned ? 1 : 0;
+    M.w[0] = wstore;
+    float totalWeight = 0.f + wstore;
+    // m >= 1: decay, prune; the loop bound is the live mode count
+#pragma unroll
+    for (int m = 1; m < kMaxModes; m++) {
+        if (__builtin_amdgcn_ballot_w64(m < nmodes) == 0)
+            break;   // (no pixel of the wave has this slot; the later ones neither)
+        const bool live = m < nmodes;
+        const float wm = k.alpha1 * M.w[m] + k.prune;
+        pruned = live && wm < negprune;
+        wstore = pruned ? 0.f : wm;
+        nmodes -= pruned ? 1 : 0;
+        M.w[m] = live ? wstore : M.w[m];
+        totalWeight += live ? wstore : 0.f;
+    }
+    float inv = 0.f;
+    if (fabsf(totalWeight) > FLT_EPSILON)
+        inv = div_normal(1.f, totalWeight);
+#pragma unroll
+    for (int m = 0; m < kMaxModes; m++) {
+        if (m > 0 && __builtin_amdgcn_ballot_w64(m < nmodes) == 0)
+            break;
+        M.w[m] = m < nmodes ? M.w[m] * inv : M.w[m];
+    }
+    nmodes_io = nmodes;
+    return true;
+}
+
+// One frame of a SETTLED wave.  The caller guarantees that every pixel of the wave
+// has exactly one mode and that its weight is exactly 1.0f (where a fitted lone
+// mode renormalises to, frame after frame).  The weight arithmetic of
+// mog2_update_single is then the same for all 64 lanes and the host has already
+// evaluated it with those very statements (FrameRates: kk1 = alphaT / wfit, wnfit =
+// the renormalised weight of the fitted mode).  If, in addition, every pixel fits
+// its mode and is background (the overwhelmingly common frame), what is left per
+// lane is the distance and the mean / variance update: the function commits that
+// and returns true -- every mask byte of the wave is 0.  Otherwise it changes
+// nothing and returns false; the caller redoes the frame with mog2_update_single.
+// `stay`: the wave is still settled after a committed frame.
+template <int C>
+__device__ __forceinline__ bool mog2_try_settled(PixelModel<C> &M, const float (&x)[C],
+                                                 const Mog2Consts &k, float var_max_v, bool &stay)
+{
+    constexpr uint32_t kOne = 0x3f800000u;
+    const float var = M.var[0];
+    float d[C];
+    float dist2;
+    if (C == 3) {
+        d[0] = M.mu[0][0] - x[0];
+        d[1] = M.mu[0][1] - x[1];
+        d[2] = M.mu[0][2] - x[2];
+        dist2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+    } else {
+        dist2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            d[c] = M.mu[0][c] - x[c];
+            dist2 += d[c] * d[c];
+        }
+    }
+    const uint64_t all = __builtin_amdgcn_ballot_w64(true);
+    // 0.f < TB on the scalar unit (a parameter, never NaN)
+    if (__float_as_int(k.TB) <= 0 || __builtin_amdgcn_ballot_w64(dist2 < k.Tg * var) != all)
+        return false;
+    // Every pixel fits.  It is background if also dist2 < Tb * var; for 0 < Tg <= Tb
+    // (positive floats order like their bit patterns; cv2's defaults are 9 and 16)
+    // that follows: dist2 >= 0, so a fit means Tg * var > 0, var > 0, and the
+    // product is monotonic in its first factor.
+    const bool implied = __float_as_int(k.Tg) > 0 && __float_as_int(k.Tb) >= __float_as_int(k.Tg);
+    if (!implied && __builtin_amdgcn_ballot_w64(dist2 < k.Tb * var) != all)
+        return false;
+#pragma unroll
+    for (int c = 0; c < C; c++)
+        M.mu[0][c] = M.mu[0][c] - k.kk1 * d[c];
+    // median of (v, var_min, var_max) instead of two compare + select pairs: the
+    // same value for every v, NaN included, given var_min <= var_max (which the host
+    // checks before it allows this path)
+    M.var[0] = __builtin_amdgcn_fmed3f(var + k.kk1 * (dist2 - var), k.var_min, var_max_v);
+    // the fitted weight; 1.0f again (what it was) whenever the wave stays settled
+    M.w[0] = k.wnfit;
+    stay = __float_as_uint(k.wnfit) == kOne;
+    return true;
+}
+
+// REFLECT_101 for a reach of one pixel: -1 -> 1, len -> len-2 (len == 1 -> 0)
+__device__ __forceinline__ int reflect1(int p, int len)
+{
+    if (p < 0)
+        return len > 1 ? 1 : 0;
+    if (p >= len)
+        return len > 1 ? len - 2 : 0;
+    return p;
+}
+
+// ---- pieces the multi-frame kernels share -------------------------------------
+// Geometry of the staged tiles: (TH + 2) x (TW + 2) px of each of up to kMaxT frames,
+// raw bytes, LDS rows of a 64-dword pitch per 64 lanes.
+template <int C, int NT = kMaxT>
+struct FrameTiles {
+    static constexpr int NDW = (((TW + 2) * C + 3 + 3) / 4 + 1 + 63) / 64;   // dwords per lane and staged row
+    static constexpr int ROWD = NDW * 64;   // LDS row pitch in dwords: every lane writes, no predicate
+    static constexpr int TILE = (TH + 2) * ROWD;
+    static constexpr int LDS_DWORDS = NT * TILE;
+    int sx0;    // first staged image column
+    int mis0;   // byte offset of that column's pixel within its aligned dword (same in every row / frame)
+
+    // Issue the loads of rows {wave, wave + 4} of all frames: two running row
+    // pointers (every staged row of every frame has the same offset mod 4, which the
+    // launcher checks), one shared lane offset, no predicates -- lanes past the
+    // row's last dword re-read it, frames past T re-read frame T - 1.
+    __device__ __forceinline__ void load(const uint8_t *frame, size_t frame_stride, int H, int W, int T,
+                                         int img, int x0, int y0, int wave, int lane,
+                                         uint32_t (&raw)[NT][2][NDW])
+    {
+        const size_t N = (size_t)H * W;
+        sx0 = x0 > 0 ? x0 - 1 : 0;
+        const int sx1 = (x0 + TW + 1) < W ? (x0 + TW + 1) : W;
+        const int nb = (sx1 - sx0) * C;
+        const uint8_t *img0 = frame + (size_t)img * N * C;
+        mis0 = (int)((uintptr_t)(img0 + (size_t)sx0 * C) & 3);
+        const int ndw = (mis0 + nb + 3) >> 2;
+        typedef const uint8_t __attribute__((address_space(1))) *GlobalBytes;
+        GlobalBytes rowp[2];
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++) {
+            const int r = wave + 4 * rr;
+            const int gy = reflect1(y0 - 1 + (r < TH + 2 ? r : 0), H);
+            const int gyc = gy < H ? gy : H - 1;   // rows below a ragged last tile
+            rowp[rr] = (GlobalBytes)(img0 + ((size_t)gyc * W + sx0) * C - mis0);
+        }
+        // (a full launch, T == NT, advances the pointers unconditionally: a third fewer
+        // scalar instructions on the path every wave of the benchmark takes)
+        if (T == NT) {
+#pragma unroll
+            for (int ti = 0; ti < NT; ti++) {
+#pragma unroll
+                for (int rr = 0; rr < 2; rr++) {
+#pragma unroll
+                    for (int q = 0; q < NDW; q++) {
+                        const unsigned d = lane + 64 * q < ndw ? lane + 64 * q : ndw - 1;
+                        raw[ti][rr][q] = *(const uint32_t __attribute__((address_space(1))) *)(rowp[rr] + d * 4u);   // SGPR base + 32-bit lane offset
+                    }
+#ifndef GOF_ABLATE_FRAME0   // (timing ablation: every frame of a launch reads frame 0's rows)
+                    if (ti + 1 < NT)
+                        rowp[rr] += frame_stride;
+#endif
+                }
+            }
+        } else {
+#pragma unroll
+            for (int ti = 0; ti < NT; ti++) {
+                const size_t step = ti + 1 < T ? frame_stride : 0;
+#pragma unroll
+                for (int rr = 0; rr < 2; rr++) {
+#pragma unroll
+                    for (int q = 0; q < NDW; q++) {
+                        const unsigned d = lane + 64 * q < ndw ? lane + 64 * q : ndw - 1;
+                        raw[ti][rr][q] = *(const uint32_t __attribute__((address_space(1))) *)(rowp[rr] + d * 4u);
+                    }
+                    rowp[rr] += step;
+                }
+            }
+        }
+    }
+
+    __device__ __forceinline__ static void store(uint32_t *tiles, int wave, int lane,
+                                                 const uint32_t (&raw)[NT][2][NDW])
+    {
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++) {
+            const int r = wave + 4 * rr;
+            if (r < TH + 2) {   // one wave-uniform test per staged row, all frames inside
+#pragma unroll
+                for (int ti = 0; ti < NT; ti++) {
+#pragma unroll
+                    for (int q = 0; q < NDW; q++)
+                        tiles[ti * TILE + r * ROWD + lane + 64 * q] = raw[ti][rr][q];
+                }
+            }
+        }
+    }
+};
+
+// Lane-invariant blur addressing.  The three pixels a lane needs from a staged row
+// (left, centre, right; the border reflection can fold left onto right) lie within
+// 12 bytes of the aligned address A below the leftmost of them.  Instead of
+// extracting them (alignbyte + byte permutes), the lane carries, per channel, a
+// 12-byte tap pattern: the horizontal pass of a row is then three v_dot4_u32_u8 per
+// channel on the three aligned dwords, nothing else.  xc: the lane's image column
+// (a lane outside the image passes the tile's first column).
+template <int C>
+struct TapPatterns {
+    uint32_t pat[C][3];
+    int A;   // byte offset of the window within a staged row
+
+    __device__ __forceinline__ void build(int xc, int W, int sx0, int mis0, uint32_t kxw)
+    {
+        const int pl = (reflect1(xc - 1, W) - sx0) * C + mis0, pc = (xc - sx0) * C + mis0,
+                  pr = (reflect1(xc + 1, W) - sx0) * C + mis0;
+        const int pmin = pl < pc ? (pl < pr ? pl : pr) : (pc < pr ? pc : pr);
+        A = pmin & ~3;
+        // channel 0: byte k0 at pl - A, k1 at pc - A, k2 at pr - A (k0 + k2 where the
+        // reflection folds them; the launcher checks that the sum fits a byte),
+        // as a 96-bit number (lo, hi); channel c is that number shifted by c bytes
+        const uint32_t kx[3] = {kxw & 255u, (kxw >> 8) & 255u, (kxw >> 16) & 255u};
+        const int rel[3] = {pl - A, pc - A, pr - A};   // each 0 .. 3 + 2 C
+        uint64_t lo = 0;
+        uint32_t hi = 0;
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+            const uint32_t sh = 8u * (uint32_t)(rel[t] & 7);
+            if (rel[t] < 8)
+                lo += (uint64_t)kx[t] << sh;
+            else
+                hi += kx[t] << sh;
+        }
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            const uint64_t l = c ? lo << (8 * c) : lo;
+            const uint32_t h = c ? (hi << (8 * c)) | (uint32_t)(lo >> (64 - 8 * c)) : hi;
+            pat[c][0] = (uint32_t)l;
+            pat[c][1] = (uint32_t)(l >> 32);
+            pat[c][2] = h;
+        }
+    }
+
+    // blurred pixel from the 3 x 3 aligned dwords at window address wa of a tile:
+    // horizontal pass as dot products against the patterns, vertical pass as 24-bit
+    // multiply-adds onto the rounding constant (`half`, 2^15 in a VGPR: the
+    // multiply-add takes one scalar operand), >> 16 -- the integer of the separable
+    // 8.8 blur of blur_kernel (sums of the same products, no intermediate rounding)
+    template <int ROWD>
+    __device__ __forceinline__ void blur(const uint32_t *tiles, uint32_t wa, const uint32_t (&ky)[3],
+                                         uint32_t half, bool batch, uint32_t (&out)[C]) const
+    {
+#ifdef GOF_ABLATE_BLUR
+        // timing ablation only (profiles/): the centre row's first three window bytes instead
+        // of the blurred pixel -- bounds what a free blur would buy; results are NOT the path's
+        {
+            const uint32_t *q = (const uint32_t *)((const char *)tiles + wa + (uint32_t)ROWD * 4u);
+            const uint32_t v = q[0];
+#pragma unroll
+            for (int c = 0; c < C; c++)
+                out[c] = (v >> (8 * (c & 3))) & 255u;
+            (void)ky;
+            (void)half;
+            (void)batch;
+            return;
+        }
+#endif
+        uint32_t win[3][3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const uint32_t *q = (const uint32_t *)((const char *)tiles + wa + (uint32_t)(j * ROWD) * 4u);
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+                win[j][i] = q[i];
+        }
+        // keeps all nine live at one point: the reads are issued back to back
+        if (batch)
+            asm volatile(""
+                         : "+v"(win[0][0]), "+v"(win[0][1]), "+v"(win[0][2]), "+v"(win[1][0]),
+                           "+v"(win[1][1]), "+v"(win[1][2]), "+v"(win[2][0]), "+v"(win[2][1]),
+                           "+v"(win[2][2]));
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            // The vertical taps of a Gaussian are symmetric (ky[0] == ky[2]; the launcher
+            // checks): rows 0 and 2 share one dot-product chain -- the accumulator carries
+            // h0 into h2 -- and one multiply-add, 2 v_mad_u32_u24 per channel instead of 3.
+            uint32_t h02 = __builtin_amdgcn_udot4(win[0][0], pat[c][0], 0u, false);
+            h02 = __builtin_amdgcn_udot4(win[0][1], pat[c][1], h02, false);
+            h02 = __builtin_amdgcn_udot4(win[0][2], pat[c][2], h02, false);
+            h02 = __builtin_amdgcn_udot4(win[2][0], pat[c][0], h02, false);
+            h02 = __builtin_amdgcn_udot4(win[2][1], pat[c][1], h02, false);
+            h02 = __builtin_amdgcn_udot4(win[2][2], pat[c][2], h02, false);
+            uint32_t h1 = __builtin_amdgcn_udot4(win[1][0], pat[c][0], 0u, false);
+            h1 = __builtin_amdgcn_udot4(win[1][1], pat[c][1], h1, false);
+            h1 = __builtin_amdgcn_udot4(win[1][2], pat[c][2], h1, false);
+            // acc += ky * h as ONE v_mad_u32_u24 each (h02 < 2^17, ky < 2^10).  The empty asm
+            // pins the running sum: without it the products are re-associated into
+            // multiply, multiply, add.  (The multiply-add itself must stay
+            // compiler-generated: a VALU read of a v_dot4 result needs wait states that
+            // only the compiler inserts.)
+            uint32_t acc = __umul24(ky[0], h02) + half;
+            asm volatile("" : "+v"(acc));
+            acc = __umul24(ky[1], h1) + acc;
+            asm volatile("" : "+v"(acc));
+            out[c] = acc >> 16;
+        }
+    }
+};
+
+
+inline dim3 grid3(int w, int h, int n, int tw, int th)
+{
+    return dim3((unsigned)((w + tw - 1) / tw), (unsigned)((h + th - 1) / th), (unsigned)n);
+}
+
+}  // namespace
+
+}  // namespace gofk

@@ -1,0 +1,289 @@
+// mog2_frames_kernel: blur 3x3 + MOG2 for up to 8 consecutive frames of every stream per
+// launch -- the kernel bench.py and ForegroundPipeline.apply_many run.  Its own translation
+// unit (compiles in seconds); the update functions live in gof_mog2_dev.h.
+// Compiled with -ffp-contract=off (see gof_mog2_dev.h / Makefile).
+#include "gof_mog2_dev.h"
+
+namespace gofk {
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// mog2_frames_kernel: the multi-frame launch on aligned frames (what bench.py and
+// ForegroundPipeline.apply_many run).  Same tile, same staging idea and the same
+// update functions as mog2_kernel<C, true, true, true>, re-written around what the
+// counters say bounds that launch: the number of vector AND scalar instructions a
+// wave issues (profiles/ DESIGN.md 5.2), not HBM.
+//   * the frame rows of all T frames are staged from two running row pointers
+//     (every row of every frame has the same offset mod 4, which the launcher
+//     checks): a handful of scalar instructions per frame instead of a 64-bit
+//     address computation per row and frame;
+//   * the per-frame rates come as one 32-byte record from the kernel-argument
+//     segment (one scalar load per frame);
+//   * lanes outside the image shadow a pixel inside it (same model, same
+//     window) and only their stores are masked, so the frame loop runs without
+//     exec-mask bookkeeping;
+//   * settled waves (every pixel one mode of weight exactly 1.0f) take the
+//     host-evaluated weight arithmetic (FrameRates) instead of two division
+//     chains per lane.
+// ---------------------------------------------------------------------------
+struct Mog2FramesArgs {
+    const uint8_t *frame;
+    uint8_t *mask;
+    float *planes;
+    uint8_t *modes;
+    size_t np, frame_stride, mask_stride;
+    int H, W, T;
+    uint32_t kxw;     // horizontal taps as bytes (k0 | k1 << 8 | k2 << 16)
+    uint32_t ky012;   // vertical taps, 10 bits each
+    uint8_t *rowflags;   // [image][row][tile column] bytes, bit t = frame t's mask not all zero there (or NULL)
+    int flag_pitch;
+    Mog2Consts k;
+};
+
+// (7 waves per SIMD for BGR: the issue-bound launch needs every one of them; the float4
+// model loads alone would let the allocator drift to 74 registers = 6 waves, 8 % slower)
+template <int C>
+__global__ __launch_bounds__(256, C <= 3 ? 7 : 1) void mog2_frames_kernel(const Mog2FramesArgs a)
+{
+    constexpr int F = 2 + C;
+    typedef FrameTiles<C> Tiles;
+    constexpr int ROWD = Tiles::ROWD, TILE = Tiles::TILE;
+    __shared__ uint32_t tiles[Tiles::LDS_DWORDS];
+
+    const int H = a.H, W = a.W, T = a.T;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    const int img = blockIdx.z;
+    const int x = x0 + lane, y = y0 + wave;
+    const size_t N = (size_t)H * W;
+
+    // ---- stage the tiles of all T frames (loads now, LDS writes after the model
+    //      loads are in flight); borders are resolved at read time ----
+    Tiles ft;
+    uint32_t raw[kMaxT][2][Tiles::NDW];
+    ft.load(a.frame, a.frame_stride, H, W, T, img, x0, y0, wave, lane, raw);
+
+    // ---- model: mode count + mode 0 speculatively, the rest only if present ----
+    const bool valid = y < H && x < W;
+    const int yy = y < H ? y : 0;
+    const unsigned xl = valid ? (unsigned)x : 0u;
+    const size_t rowoff = (size_t)img * N + (size_t)yy * W;   // wave-uniform
+    float *const planes_ = a.planes;
+    float *const prow = a.planes + rowoff;
+    const size_t np = a.np;
+    PixelModel<C> M;
+    const int mbyte_in = (int)a.modes[rowoff + xl];   // mode count | kW0One (see mog2_kernel)
+    int nmodes = mbyte_in & kModeCount;
+    load_mode_vec<C>(planes_, np, rowoff + xl, M.var[0], M.mu[0]);
+    M.w[0] = 1.f;
+    if (__builtin_amdgcn_ballot_w64(!(mbyte_in & kW0One)) != 0)
+        M.w[0] = prow[xl];
+    const uint32_t w0_in = __float_as_uint(M.w[0]);
+    // slots 1.. are loaded only if some pixel of the wave has them; otherwise slot 1
+    // starts empty (the single-mode loops may fill it) and slots 2.. stay untouched
+    // until the general loop is entered
+    // the staged rows go to LDS before the further modes are asked for: the 16 staging
+    // registers are free again by then (settled waves, four in five, load no further mode)
+    Tiles::store(tiles, wave, lane, raw);
+    const bool multi_in = __builtin_amdgcn_ballot_w64(nmodes > 1) != 0;
+    if (multi_in) {
+#pragma unroll
+        for (int m = 1; m < kMaxModes; m++) {
+            if (m < nmodes) {
+                const float *pm = planes_ + (size_t)m * F * np;
+                M.w[m] = pm[rowoff + xl];
+                load_mode_vec<C>(pm, np, rowoff + xl, M.var[m], M.mu[m]);
+            } else {
+                M.w[m] = 0.f;
+                M.var[m] = 0.f;
+#pragma unroll
+                for (int c = 0; c < C; c++)
+                    M.mu[m][c] = 0.f;
+            }
+        }
+    } else {
+        M.w[1] = 0.f;
+        M.var[1] = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; c++)
+            M.mu[1][c] = 0.f;
+    }
+
+
+    // lane-invariant tap patterns; a lane outside the image shadows the tile's first pixel
+    TapPatterns<C> taps;
+    taps.build(valid ? x : x0, W, ft.sx0, ft.mis0, a.kxw);
+    uint32_t wa = (uint32_t)(wave * ROWD) * 4u + (uint32_t)taps.A;   // window address, current frame
+    uint32_t half = 32768u;
+    float var_max_v = a.k.var_max;   // (the clamp takes one scalar operand, var_min)
+    asm volatile("" : "+v"(half), "+v"(var_max_v));   // kept in registers, not re-materialised per use
+    const uint32_t ky[3] = {a.ky012 & 1023u, (a.ky012 >> 10) & 1023u, a.ky012 >> 20};
+
+    __syncthreads();   // the only barrier: every tile is in LDS
+
+    // blurred pixel of the current frame as floats (batch: the nine LDS reads issued
+    // back to back -- not in the general loop, which has the whole mixture in registers)
+    auto frame_input = [&](float (&xin)[C], bool batch) {
+        uint32_t v[C];
+        taps.template blur<ROWD>(tiles, wa, ky, half, batch, v);
+        wa += (uint32_t)TILE * 4u;   // next frame
+#pragma unroll
+        for (int c = 0; c < C; c++)
+            xin[c] = (float)v[c];
+    };
+    // The frame's scalars: one 32-byte scalar load from the argument segment,
+    // requested one frame ahead (the record of frame ti + 1 travels while frame ti
+    // is computed; a load placed in the iteration that uses it gets sunk to its
+    // first use and its latency lands on the critical path).
+    typedef const Mog2FramesArgs __attribute__((address_space(4))) *ArgsPtr;
+    const ArgsPtr ap = (ArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+    auto load_rates = [&](int ti) -> u32x8 {
+        const int tc = ti < kMaxT ? ti : kMaxT - 1;
+        return *(const u32x8 __attribute__((address_space(4))) *)&ap->k.fr[tc];
+    };
+    auto frame_consts = [&](const u32x8 &r) -> Mog2Consts {
+        Mog2Consts kt = a.k;
+        kt.alphaT = __uint_as_float(r[0]);
+        kt.alpha1 = __uint_as_float(r[1]);
+        kt.prune = __uint_as_float(r[2]);
+        kt.kk1 = __uint_as_float(r[3]);
+        kt.wnfit = __uint_as_float(r[4]);
+        kt.wnmiss = __uint_as_float(r[5]);
+        kt.uni_ok = r[6];
+        return kt;
+    };
+    // this wave's row in the mask of the current frame: a wave-uniform base (scalar registers,
+    // advanced per frame on the scalar unit) + the lane's 32-bit offset
+    uint8_t *mrow = a.mask + rowoff;
+
+    // Three frame loops, entered in this order and never re-entered: settled waves,
+    // then waves whose pixels all have at most one mode, then the general update.
+    int ti = 0;
+    uint32_t nz = 0;   // bit t: some mask byte of frame t is not zero in this wave (wave-uniform)
+    u32x8 rates = load_rates(0);
+    // settled on entry?  Afterwards mog2_try_settled reports it frame by frame.
+    bool settled = __builtin_amdgcn_ballot_w64(!(nmodes == 1 && M.w[0] == 1.f)) == 0;
+    // (a.k.uni_mask: the frames whose rates allow the shortcut, known before the
+    // frame's record arrives)
+    while (settled && ti < T && ((a.k.uni_mask >> ti) & 1u) != 0) {
+        const u32x8 next = load_rates(ti + 1);
+        const Mog2Consts kt = frame_consts(rates);
+        float xin[C];
+        frame_input(xin, true);
+        if (!mog2_try_settled<C>(M, xin, kt, var_max_v, settled)) {
+            // some pixel missed its mode or is not background: redo the frame below
+            wa -= (uint32_t)TILE * 4u;
+            break;
+        }
+        if (valid)
+            mrow[xl] = 0;
+        mrow += a.mask_stride;
+        rates = next;
+        ti++;
+    }
+    for (; ti < T; ti++) {
+        if (__builtin_amdgcn_ballot_w64(nmodes > 1) != 0)
+            break;
+        const u32x8 next = load_rates(ti + 1);
+        const Mog2Consts kt = frame_consts(rates);
+        float xin[C];
+        frame_input(xin, true);
+        const uint8_t out = mog2_update_single<C>(M, nmodes, xin, kt);
+        nz |= (__builtin_amdgcn_ballot_w64(out != 0) != 0 ? 1u : 0u) << ti;
+        if (valid)
+            mrow[xl] = out;
+        mrow += a.mask_stride;
+        rates = next;
+    }
+    if (!multi_in && ti < T) {
+#pragma unroll
+        for (int m = 2; m < kMaxModes; m++) {
+            M.w[m] = 0.f;
+            M.var[m] = 0.f;
+#pragma unroll
+            for (int c = 0; c < C; c++)
+                M.mu[m][c] = 0.f;
+        }
+    }
+    for (; ti < T; ti++) {
+        const u32x8 next = load_rates(ti + 1);
+        const Mog2Consts kt = frame_consts(rates);
+        float xin[C];
+        frame_input(xin, false);
+        // (waves on an object's trail, most frames: every first mode fits)
+        uint8_t out = 0;
+        if (!mog2_try_first_fits<C>(M, nmodes, xin, kt))
+            out = mog2_update<C, kMaxModes>(M, nmodes, xin, kt);
+        nz |= (__builtin_amdgcn_ballot_w64(out != 0) != 0 ? 1u : 0u) << ti;
+        if (valid)
+            mrow[xl] = out;
+        mrow += a.mask_stride;
+        rates = next;
+    }
+    // one flag byte per wave and launch for the morphology that follows (the settled
+    // loop only ever writes zeros, so it contributes no bits)
+    if (a.rowflags != nullptr && y < H && lane == 0)
+        a.rowflags[((size_t)img * H + y) * a.flag_pitch + blockIdx.x] = (uint8_t)nz;
+    if (!valid)
+        return;
+
+    // planes no pixel of the wave changed are not written back (see mog2_kernel)
+    const bool w0_dirty = __builtin_amdgcn_ballot_w64(nmodes > 0 && __float_as_uint(M.w[0]) != w0_in) != 0;
+    const int mbyte = nmodes | ((nmodes > 0 && __float_as_uint(M.w[0]) == 0x3f800000u) ? kW0One : 0);
+    const bool nm_dirty = __builtin_amdgcn_ballot_w64(mbyte != mbyte_in) != 0;
+#pragma unroll
+    for (int m = 0; m < kMaxModes; m++) {
+        if (m < nmodes) {
+            float *pm = planes_ + (size_t)m * F * np;
+            if (m > 0 || w0_dirty)
+                pm[rowoff + xl] = M.w[m];
+            store_mode_vec<C>(pm, np, rowoff + xl, M.var[m], M.mu[m]);
+        }
+    }
+    if (nm_dirty)
+        a.modes[rowoff + xl] = (uint8_t)mbyte;
+}
+
+}  // namespace
+
+// Launch; mog2_apply (gof_mog2.hip) has checked the shapes and that every staged row of every
+// frame starts at the same offset mod 4, the taps are bytes whose folded outer pair fits a
+// byte, the vertical taps are symmetric, 2 <= T <= kMaxT and w > 1.
+hipError_t mog2_frames_launch(const uint8_t *frame, uint8_t *mask, const Mog2State &st, int n_img, int h,
+                              int w, int c, int T, const Mog2Consts &k, const Taps &t, hipStream_t s,
+                              uint8_t *rowflags)
+{
+    if (n_img < 1 || h < 1 || w < 2 || T < 2 || T > kMaxT || (h + TH - 1) / TH > 65535 || n_img > 65535 ||
+        st.np < (size_t)n_img * h * w || t.nkx != 3 || t.nky != 3 || t.kx[0] + t.kx[2] > 255 ||
+        t.kx[1] > 255 || t.ky[0] != t.ky[2])
+        return hipErrorInvalidValue;
+    Mog2FramesArgs a;
+    a.frame = frame;
+    a.mask = mask;
+    a.planes = st.planes;
+    a.modes = st.modes;
+    a.np = st.np;
+    a.frame_stride = (size_t)n_img * h * w * c;
+    a.mask_stride = (size_t)n_img * h * w;
+    a.H = h;
+    a.W = w;
+    a.T = T;
+    a.kxw = (uint32_t)t.kx[0] | ((uint32_t)t.kx[1] << 8) | ((uint32_t)t.kx[2] << 16);
+    a.ky012 = t.ky[0] | (t.ky[1] << 10) | (t.ky[2] << 20);
+    a.rowflags = rowflags;
+    a.flag_pitch = rowflag_pitch(w);
+    a.k = k;
+    const dim3 g = grid3(w, h, n_img, TW, TH);
+    switch (c) {
+    case 1: hipLaunchKernelGGL(mog2_frames_kernel<1>, g, dim3(256), 0, s, a); break;
+    case 3: hipLaunchKernelGGL(mog2_frames_kernel<3>, g, dim3(256), 0, s, a); break;
+    case 4: hipLaunchKernelGGL(mog2_frames_kernel<4>, g, dim3(256), 0, s, a); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace gofk
