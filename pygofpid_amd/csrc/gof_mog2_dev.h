@@ -28,6 +28,30 @@ constexpr int TH = 4;
 // without the bit only costs a read of the weight plane)
 constexpr int kModeCount = 0x7f, kW0One = 0x80;
 
+// Path statistics of the multi-frame kernel (profiles/micro/path_stats.py; -DGOF_PATH_STATS builds
+// only, never the product library): wave-uniform counts kept in scalar registers, one atomic per
+// counter and wave at the end.  The macros vanish in the product build.
+#ifdef GOF_PATH_STATS
+struct PathStats {
+    uint32_t v[32];
+};
+enum {
+    kStSettled, kStSingle, kStFirstFits, kStGeneral, kStGenLanesNotOk, kStGenInsert, kStGenReorder,
+    kStGenNotBg, kStGenLanesNotBg, kStGenSumMaxModes, kStGenFitLate, kStGenSlot1, kStGenSlot2, kStGenSlot3,
+    kStGenSlot4, kStWaves, kStWavesMulti, kStFit0, kStFit1, kStFit2, kStFit3, kStFit4, kStShadowIters,
+    kStGenLanesInsert, kStInsertReorder, kStCount
+};
+#define GOF_STAT_ARG , PathStats &ps
+#define GOF_STAT_PASS , ps
+#define GOF_STAT(i, x) ps.v[i] += (uint32_t)(x)
+#define GOF_ANY(c) (__builtin_amdgcn_ballot_w64(c) != 0 ? 1u : 0u)
+#define GOF_POP(c) ((uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(c)))
+#else
+#define GOF_STAT_ARG
+#define GOF_STAT_PASS
+#define GOF_STAT(i, x) ((void)0)
+#endif
+
 template <int C>
 struct PixelModel {
     float w[kMaxModes];
@@ -93,6 +117,65 @@ __device__ __forceinline__ void store_mode_vec(float *mode, size_t np, size_t pi
     }
 }
 
+// The same through the wave's row: `rowoff` = pixel index of the row's first pixel (wave-uniform, so
+// the plane's row base sits in scalar registers) and the lane's column `xl` -- a global access with
+// an SGPR base and a 32-bit VGPR byte offset (the offset is formed in 32-bit arithmetic: a row is
+// far below 2^32 bytes), no 64-bit per-lane address kept live across the frame loops.
+typedef const char __attribute__((address_space(1))) *GlobalRow;
+typedef char __attribute__((address_space(1))) *GlobalRowW;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// (the empty asm pins the base as ONE scalar value: otherwise the bases of the mode planes are
+// re-associated into a shared per-lane 64-bit address plus scalar deltas, and the access falls
+// back to a 64-bit VGPR address; it pins the 32-bit offset in the block of the access, where
+// instruction selection has to see its zero extension.  row_base MUST be wave-uniform.)
+template <typename T>
+__device__ __forceinline__ T row_load(const void *row_base, unsigned byte_off)
+{
+    GlobalRow b = (GlobalRow)row_base;
+    asm("" : "+s"(b), "+v"(byte_off));
+    return *(const T __attribute__((address_space(1))) *)(b + byte_off);
+}
+template <typename T>
+__device__ __forceinline__ void row_store(void *row_base, unsigned byte_off, T v)
+{
+    GlobalRowW b = (GlobalRowW)row_base;
+    asm("" : "+s"(b), "+v"(byte_off));
+    *(T __attribute__((address_space(1))) *)(b + byte_off) = v;
+}
+
+template <int C>
+__device__ __forceinline__ void load_mode_vec_row(const float *mode, size_t np, size_t rowoff, unsigned xl,
+                                                  float &var, float (&mu)[C])
+{
+    if (C == 1) {
+        const f32x2 q = row_load<f32x2>((const float2 *)(mode + np) + rowoff, xl * 8u);
+        var = q.x;
+        mu[0] = q.y;
+    } else {
+        const f32x4 q = row_load<f32x4>((const float4 *)(mode + np) + rowoff, xl * 16u);
+        var = q.x;
+        mu[0] = q.y;
+        mu[1 % C] = q.z;
+        mu[2 % C] = q.w;
+        if (C == 4)
+            mu[3 % C] = row_load<float>(mode + 5 * np + rowoff, xl * 4u);
+    }
+}
+
+template <int C>
+__device__ __forceinline__ void store_mode_vec_row(float *mode, size_t np, size_t rowoff, unsigned xl, float var,
+                                                   const float (&mu)[C])
+{
+    if (C == 1) {
+        row_store<f32x2>((float2 *)(mode + np) + rowoff, xl * 8u, f32x2{var, mu[0]});
+    } else {
+        row_store<f32x4>((float4 *)(mode + np) + rowoff, xl * 16u, f32x4{var, mu[0], mu[1 % C], mu[2 % C]});
+        if (C == 4)
+            row_store<float>(mode + 5 * np + rowoff, xl * 4u, mu[3 % C]);
+    }
+}
+
 // IEEE-correct a / b for operands in the normal range with a normal quotient:
 // the Newton / residual chain hipcc itself emits for a float division, without
 // its range scaling (v_div_scale, v_div_fmas' scale) and special-case fix-up
@@ -115,7 +198,7 @@ __device__ __forceinline__ float div_normal(float a, float b)
 // this frame's update.  Returns true for a shadow pixel.
 template <int C, int LIM>
 __device__ __forceinline__ bool shadow_test(const PixelModel<C> &M, int nmodes, const float (&x)[C],
-                                            const Mog2Consts &k)
+                                            const Mog2Consts &k GOF_STAT_ARG)
 {
     bool shadow = false;
     if (k.detect_shadows) {
@@ -123,6 +206,9 @@ __device__ __forceinline__ bool shadow_test(const PixelModel<C> &M, int nmodes, 
         bool done = false;
 #pragma unroll
         for (int m = 0; m < LIM; m++) {
+#ifdef GOF_PATH_STATS
+            ps.v[31] |= (!done && m < nmodes) ? 1u << m : 0u;   // per lane: the slots this lane examined
+#endif
             if (!done && m < nmodes) {
                 float num = 0.f, den = 0.f;
 #pragma unroll
@@ -169,9 +255,16 @@ __device__ __forceinline__ bool shadow_test(const PixelModel<C> &M, int nmodes, 
 // (four waves out of five on surveillance footage): same statements, same
 // order, same results, but only the slots that can be live (0 on entry, 0..1 on
 // exit) are ever touched, which removes most of the unrolled predication.
-template <int C, int MAXIN>
+//
+// What a wave rarely does sits behind wave-uniform branches (ballots), so that the common frame
+// does not pay for it in selects: re-ordering after a fit (a position of the bubble-up is entered
+// only if some lane moves there), opening a new mode, and the re-ordering behind that.
+// MED3: the caller guarantees var_min <= var_max (the launcher checks), so that the variance
+// clamp is one v_med3_f32 -- the same value as the two compare / select pairs for every input,
+// NaN included (mog2_try_settled).
+template <int C, int MAXIN, bool MED3 = false>
 __device__ __forceinline__ uint8_t mog2_update(PixelModel<C> &M, int &nmodes_io, const float (&x)[C],
-                                               const Mog2Consts &k)
+                                               const Mog2Consts &k GOF_STAT_ARG)
 {
     constexpr int LIN = MAXIN < kMaxModes ? MAXIN : kMaxModes;            // live slots on entry
     constexpr int LOUT = MAXIN + 1 < kMaxModes ? MAXIN + 1 : kMaxModes;   // ... after an insertion
@@ -179,9 +272,23 @@ __device__ __forceinline__ uint8_t mog2_update(PixelModel<C> &M, int &nmodes_io,
     bool background = false, fits = false;
     float totalWeight = 0.f;
     const float negprune = -k.prune;
+#ifdef GOF_PATH_STATS
+    {
+        int mx = 0;
+#pragma unroll
+        for (int m = 1; m <= kMaxModes; m++)
+            mx = __builtin_amdgcn_ballot_w64(nmodes >= m) != 0 ? m : mx;
+        ps.v[kStGenSumMaxModes] += (uint32_t)mx;
+    }
+    bool st_reorder = false, st_late = false;
+#endif
 
 #pragma unroll
     for (int m = 0; m < LIN; m++) {
+#ifdef GOF_PATH_STATS
+        if (m > 0)
+            ps.v[kStGenSlot1 + m - 1] += GOF_ANY(m < nmodes);
+#endif
         if (m < nmodes) {  // live bound: nmodes shrinks when a mode is pruned
             float weight = k.alpha1 * M.w[m] + k.prune;
             bool fit_here = false;
@@ -213,8 +320,12 @@ __device__ __forceinline__ uint8_t mog2_update(PixelModel<C> &M, int &nmodes_io,
                     for (int c = 0; c < C; c++)
                         M.mu[m][c] -= kk * d[c];
                     float varnew = var + kk * (dist2 - var);
-                    varnew = varnew > k.var_min ? varnew : k.var_min;
-                    varnew = varnew > k.var_max ? k.var_max : varnew;
+                    if (MED3) {
+                        varnew = __builtin_amdgcn_fmed3f(varnew, k.var_min, k.var_max);
+                    } else {
+                        varnew = varnew > k.var_min ? varnew : k.var_min;
+                        varnew = varnew > k.var_max ? k.var_max : varnew;
+                    }
                     M.var[m] = varnew;
                 }
             }
@@ -225,55 +336,97 @@ __device__ __forceinline__ uint8_t mog2_update(PixelModel<C> &M, int &nmodes_io,
             }
             M.w[m] = wstore;
             totalWeight += wstore;
-            if (fit_here) {
-                bool go = true;
+            // bubble the fitted mode up while its weight is not below its predecessor's: a
+            // position is entered only if some lane of the wave moves there (rare)
+            if (m > 0 && __builtin_amdgcn_ballot_w64(fit_here && !(weight < M.w[m - 1])) != 0) {
+                bool go = fit_here;
 #pragma unroll
                 for (int i = m; i > 0; i--) {
                     go = go && !(weight < M.w[i - 1]);
+                    if (i < m && __builtin_amdgcn_ballot_w64(go) == 0)
+                        break;
+#ifdef GOF_PATH_STATS
+                    st_reorder = st_reorder || go;
+#endif
                     swap_modes<C>(M, i, go);
                 }
             }
+#ifdef GOF_PATH_STATS
+            st_late = st_late || (fit_here && m > 0);
+            ps.v[kStFit0 + m] += GOF_POP(fit_here);
+#endif
         }
     }
+    GOF_STAT(kStGenReorder, GOF_ANY(st_reorder));
+    GOF_STAT(kStGenFitLate, GOF_ANY(st_late));
+    GOF_STAT(kStGenInsert, GOF_ANY(!fits && k.alphaT > 0.f));
+    GOF_STAT(kStGenLanesInsert, GOF_POP(!fits && k.alphaT > 0.f));
+    GOF_STAT(kStGenNotBg, GOF_ANY(!background));
+    GOF_STAT(kStGenLanesNotBg, GOF_POP(!background));
 
     float inv = 0.f;
     if (fabsf(totalWeight) > FLT_EPSILON)
         inv = div_normal(1.f, totalWeight);
+    // (slots at or beyond the mode count are dead storage -- never read before a new mode
+    // rewrites every field of them, never stored -- so they are scaled along: no per-slot test)
 #pragma unroll
     for (int m = 0; m < LIN; m++)
-        if (m < nmodes)
-            M.w[m] *= inv;
+        M.w[m] *= inv;
 
-    if (!fits && k.alphaT > 0.f) {
-        int slot = nmodes == k.nmix ? k.nmix - 1 : nmodes++;
-        bool first = nmodes == 1;
+    // a new mode where nothing fitted: the last slot (replacing the weakest mode when all nmix
+    // are in use); the modes in front of it decay once more; then it is bubbled up like a fit
+    const bool need = !fits && k.alphaT > 0.f;
+    if (__builtin_amdgcn_ballot_w64(need) != 0) {   // wave-uniform: some pixel opens a new mode
+        int slot = -1;
+        if (need) {
+            slot = nmodes == k.nmix ? k.nmix - 1 : nmodes++;   // == the new count - 1
+            const float w_new = slot == 0 ? 1.f : k.alphaT;
 #pragma unroll
-        for (int m = 0; m < LOUT; m++) {
-            if (m == slot) {
-                M.w[m] = first ? 1.f : k.alphaT;
-                M.var[m] = k.var_init;
+            for (int m = 0; m < LOUT; m++) {
+                const bool here = m == slot;
+                M.w[m] = here ? w_new : (m < slot ? M.w[m] * k.alpha1 : M.w[m]);
+                M.var[m] = here ? k.var_init : M.var[m];
 #pragma unroll
                 for (int c = 0; c < C; c++)
-                    M.mu[m][c] = x[c];
-            } else if (!first && m < nmodes - 1) {
-                M.w[m] *= k.alpha1;
+                    M.mu[m][c] = here ? x[c] : M.mu[m][c];
             }
         }
-        bool go = true;
+        bool go = need;
+#ifdef GOF_PATH_STATS
+        bool st_sw = false;
+#endif
 #pragma unroll
         for (int i = LOUT - 1; i > 0; i--) {
-            bool in = i <= nmodes - 1;
-            bool sw = in && go && !(k.alphaT < M.w[i - 1]);
-            if (in)
-                go = sw;
-            swap_modes<C>(M, i, sw);
+            // position i is the new mode's only while every swap above it happened
+            const bool sw = go && i <= slot && !(k.alphaT < M.w[i - 1]);
+            go = i <= slot ? sw : go;
+            if (__builtin_amdgcn_ballot_w64(sw) != 0)
+                swap_modes<C>(M, i, sw);
+#ifdef GOF_PATH_STATS
+            st_sw = st_sw || sw;
+#endif
         }
+        GOF_STAT(kStInsertReorder, GOF_ANY(st_sw));
     }
     nmodes_io = nmodes;
 
+#ifdef GOF_PATH_STATS
+    {   // the shadow test, run here so that the per-lane slot bits can be counted wave-uniformly
+        PathStats pl;
+        pl.v[31] = 0;
+        uint8_t out = 0;
+        if (!background)
+            out = shadow_test<C, LOUT>(M, nmodes, x, k, pl) ? (uint8_t)k.shadow_value : (uint8_t)255;
+#pragma unroll
+        for (int m = 0; m < kMaxModes; m++)
+            ps.v[kStShadowIters] += GOF_ANY(!background && ((pl.v[31] >> m) & 1u));
+        return out;
+    }
+#else
     if (background)
         return 0;
     return shadow_test<C, LOUT>(M, nmodes, x, k) ? (uint8_t)k.shadow_value : (uint8_t)255;
+#endif
 }
 
 // The MAXIN = 1 instance of mog2_update written without per-lane branches on the
@@ -283,7 +436,7 @@ __device__ __forceinline__ uint8_t mog2_update(PixelModel<C> &M, int &nmodes_io,
 // pixel -- sit behind wave-uniform branches.  On a wave of pure background this
 // is a straight line of ~70 vector instructions and no exec-mask bookkeeping,
 // which matters because the multi-frame kernel is bound by VALU + SALU issue.
-template <int C>
+template <int C, bool MED3 = false>
 __device__ __forceinline__ uint8_t mog2_update_single(PixelModel<C> &M, int &nmodes_io,
                                                       const float (&x)[C], const Mog2Consts &k)
 {
@@ -313,8 +466,12 @@ __device__ __forceinline__ uint8_t mog2_update_single(PixelModel<C> &M, int &nmo
             M.mu[0][c] = fit ? mnew : M.mu[0][c];
         }
         float varnew = var + kk * (dist2 - var);
-        varnew = varnew > k.var_min ? varnew : k.var_min;
-        varnew = varnew > k.var_max ? k.var_max : varnew;
+        if (MED3) {
+            varnew = __builtin_amdgcn_fmed3f(varnew, k.var_min, k.var_max);
+        } else {
+            varnew = varnew > k.var_min ? varnew : k.var_min;
+            varnew = varnew > k.var_max ? k.var_max : varnew;
+        }
         M.var[0] = fit ? varnew : var;
     };
     bool background, fit;
@@ -365,7 +522,15 @@ __device__ __forceinline__ uint8_t mog2_update_single(PixelModel<C> &M, int &nmo
     uint8_t out = 0;
     if (__builtin_amdgcn_ballot_w64(!background) != 0) {   // wave-uniform: some pixel is not background
         if (!background)
-            out = shadow_test<C, 2>(M, nmodes, x, k) ? (uint8_t)k.shadow_value : (uint8_t)255;
+        {
+#ifdef GOF_PATH_STATS
+            PathStats ps;   // (not counted: the single-mode loop's shadow tests)
+#pragma unroll
+            for (int i = 0; i < 32; i++)
+                ps.v[i] = 0;
+#endif
+            out = shadow_test<C, 2>(M, nmodes, x, k GOF_STAT_PASS) ? (uint8_t)k.shadow_value : (uint8_t)255;
+        }
     }
     return out;
 }
@@ -379,9 +544,9 @@ __device__ __forceinline__ uint8_t mog2_update_single(PixelModel<C> &M, int &nmo
 // grows, the others shrink together), no shadow test runs, every mask byte is 0.  Written as
 // a straight line with selects, slots beyond the wave's largest mode count skipped by
 // wave-uniform branches.  Returns false -- nothing changed -- if some pixel does not fit.
-template <int C>
+template <int C, bool MED3 = false>
 __device__ __forceinline__ bool mog2_try_first_fits(PixelModel<C> &M, int &nmodes_io, const float (&x)[C],
-                                                    const Mog2Consts &k)
+                                                    const Mog2Consts &k GOF_STAT_ARG)
 {
     const float var = M.var[0];
     float d[C];
@@ -402,8 +567,10 @@ __device__ __forceinline__ bool mog2_try_first_fits(PixelModel<C> &M, int &nmode
     int nmodes = nmodes_io;
     // every pixel: a first mode, which fits, and background (totalWeight = 0 < TB, dist2 < Tb var)
     const bool ok = nmodes > 0 && dist2 < k.Tg * var && dist2 < k.Tb * var;
-    if (__float_as_int(k.TB) <= 0 || __builtin_amdgcn_ballot_w64(!ok) != 0)
+    if (__float_as_int(k.TB) <= 0 || __builtin_amdgcn_ballot_w64(!ok) != 0) {
+        GOF_STAT(kStGenLanesNotOk, GOF_POP(!ok));
         return false;
+    }
     const float negprune = -k.prune;
     // m = 0, the fitted mode
     float weight = k.alpha1 * M.w[0] + k.prune;
@@ -413,8 +580,12 @@ __device__ __forceinline__ bool mog2_try_first_fits(PixelModel<C> &M, int &nmode
     for (int c = 0; c < C; c++)
         M.mu[0][c] -= kk * d[c];
     float varnew = var + kk * (dist2 - var);
-    varnew = varnew > k.var_min ? varnew : k.var_min;
-    varnew = varnew > k.var_max ? k.var_max : varnew;
+    if (MED3) {
+        varnew = __builtin_amdgcn_fmed3f(varnew, k.var_min, k.var_max);
+    } else {
+        varnew = varnew > k.var_min ? varnew : k.var_min;
+        varnew = varnew > k.var_max ? k.var_max : varnew;
+    }
     M.var[0] = varnew;
     bool pruned = weight < negprune;
     float wstore = pruned ? 0.f : weight;

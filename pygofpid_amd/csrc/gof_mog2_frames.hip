@@ -27,6 +27,10 @@ namespace {
 //     host-evaluated weight arithmetic (FrameRates) instead of two division
 //     chains per lane.
 // ---------------------------------------------------------------------------
+#ifdef GOF_PATH_STATS
+__device__ unsigned long long g_path_stats[32];
+#endif
+
 struct Mog2FramesArgs {
     const uint8_t *frame;
     uint8_t *mask;
@@ -43,8 +47,11 @@ struct Mog2FramesArgs {
 
 // (7 waves per SIMD for BGR: the issue-bound launch needs every one of them; the float4
 // model loads alone would let the allocator drift to 74 registers = 6 waves, 8 % slower)
+#ifndef GOF_FRAMES_WAVES
+#define GOF_FRAMES_WAVES 7   // (A/B knob of profiles/: waves per SIMD the register allocation aims at)
+#endif
 template <int C>
-__global__ __launch_bounds__(256, C <= 3 ? 7 : 1) void mog2_frames_kernel(const Mog2FramesArgs a)
+__global__ __launch_bounds__(256, C <= 3 ? GOF_FRAMES_WAVES : 1) void mog2_frames_kernel(const Mog2FramesArgs a)
 {
     constexpr int F = 2 + C;
     typedef FrameTiles<C> Tiles;
@@ -74,12 +81,13 @@ __global__ __launch_bounds__(256, C <= 3 ? 7 : 1) void mog2_frames_kernel(const 
     float *const prow = a.planes + rowoff;
     const size_t np = a.np;
     PixelModel<C> M;
-    const int mbyte_in = (int)a.modes[rowoff + xl];   // mode count | kW0One (see mog2_kernel)
+    uint8_t *const mrow_modes = a.modes + rowoff;     // (wave-uniform row bases + the lane's 32-bit column)
+    const int mbyte_in = (int)row_load<uint8_t>(mrow_modes, xl);         // mode count | kW0One (see mog2_kernel)
     int nmodes = mbyte_in & kModeCount;
-    load_mode_vec<C>(planes_, np, rowoff + xl, M.var[0], M.mu[0]);
+    load_mode_vec_row<C>(planes_, np, rowoff, xl, M.var[0], M.mu[0]);
     M.w[0] = 1.f;
     if (__builtin_amdgcn_ballot_w64(!(mbyte_in & kW0One)) != 0)
-        M.w[0] = prow[xl];
+        M.w[0] = row_load<float>(prow, xl * 4u);
     const uint32_t w0_in = __float_as_uint(M.w[0]);
     // slots 1.. are loaded only if some pixel of the wave has them; otherwise slot 1
     // starts empty (the single-mode loops may fill it) and slots 2.. stay untouched
@@ -93,8 +101,8 @@ __global__ __launch_bounds__(256, C <= 3 ? 7 : 1) void mog2_frames_kernel(const 
         for (int m = 1; m < kMaxModes; m++) {
             if (m < nmodes) {
                 const float *pm = planes_ + (size_t)m * F * np;
-                M.w[m] = pm[rowoff + xl];
-                load_mode_vec<C>(pm, np, rowoff + xl, M.var[m], M.mu[m]);
+                M.w[m] = row_load<float>(pm + rowoff, xl * 4u);
+                load_mode_vec_row<C>(pm, np, rowoff, xl, M.var[m], M.mu[m]);
             } else {
                 M.w[m] = 0.f;
                 M.var[m] = 0.f;
@@ -163,6 +171,14 @@ __global__ __launch_bounds__(256, C <= 3 ? 7 : 1) void mog2_frames_kernel(const 
     // then waves whose pixels all have at most one mode, then the general update.
     int ti = 0;
     uint32_t nz = 0;   // bit t: some mask byte of frame t is not zero in this wave (wave-uniform)
+#ifdef GOF_PATH_STATS
+    PathStats ps;
+#pragma unroll
+    for (int i = 0; i < 32; i++)
+        ps.v[i] = 0;
+    ps.v[kStWaves] = 1;
+    ps.v[kStWavesMulti] = multi_in ? 1u : 0u;
+#endif
     u32x8 rates = load_rates(0);
     // settled on entry?  Afterwards mog2_try_settled reports it frame by frame.
     bool settled = __builtin_amdgcn_ballot_w64(!(nmodes == 1 && M.w[0] == 1.f)) == 0;
@@ -179,10 +195,11 @@ __global__ __launch_bounds__(256, C <= 3 ? 7 : 1) void mog2_frames_kernel(const 
             break;
         }
         if (valid)
-            mrow[xl] = 0;
+            row_store<uint8_t>(mrow, xl, (uint8_t)0);
         mrow += a.mask_stride;
         rates = next;
         ti++;
+        GOF_STAT(kStSettled, 1);
     }
     for (; ti < T; ti++) {
         if (__builtin_amdgcn_ballot_w64(nmodes > 1) != 0)
@@ -191,10 +208,11 @@ __global__ __launch_bounds__(256, C <= 3 ? 7 : 1) void mog2_frames_kernel(const 
         const Mog2Consts kt = frame_consts(rates);
         float xin[C];
         frame_input(xin, true);
-        const uint8_t out = mog2_update_single<C>(M, nmodes, xin, kt);
+        const uint8_t out = mog2_update_single<C, true>(M, nmodes, xin, kt);
+        GOF_STAT(kStSingle, 1);
         nz |= (__builtin_amdgcn_ballot_w64(out != 0) != 0 ? 1u : 0u) << ti;
         if (valid)
-            mrow[xl] = out;
+            row_store<uint8_t>(mrow, xl, out);
         mrow += a.mask_stride;
         rates = next;
     }
@@ -215,11 +233,15 @@ __global__ __launch_bounds__(256, C <= 3 ? 7 : 1) void mog2_frames_kernel(const 
         frame_input(xin, false);
         // (waves on an object's trail, most frames: every first mode fits)
         uint8_t out = 0;
-        if (!mog2_try_first_fits<C>(M, nmodes, xin, kt))
-            out = mog2_update<C, kMaxModes>(M, nmodes, xin, kt);
+        if (!mog2_try_first_fits<C, true>(M, nmodes, xin, kt GOF_STAT_PASS)) {
+            GOF_STAT(kStGeneral, 1);
+            out = mog2_update<C, kMaxModes, true>(M, nmodes, xin, kt GOF_STAT_PASS);
+        } else {
+            GOF_STAT(kStFirstFits, 1);
+        }
         nz |= (__builtin_amdgcn_ballot_w64(out != 0) != 0 ? 1u : 0u) << ti;
         if (valid)
-            mrow[xl] = out;
+            row_store<uint8_t>(mrow, xl, out);
         mrow += a.mask_stride;
         rates = next;
     }
@@ -227,6 +249,14 @@ __global__ __launch_bounds__(256, C <= 3 ? 7 : 1) void mog2_frames_kernel(const 
     // loop only ever writes zeros, so it contributes no bits)
     if (a.rowflags != nullptr && y < H && lane == 0)
         a.rowflags[((size_t)img * H + y) * a.flag_pitch + blockIdx.x] = (uint8_t)nz;
+#ifdef GOF_PATH_STATS
+    if (lane == 0 && y < H) {
+#pragma unroll
+        for (int i = 0; i < kStCount; i++)
+            if (ps.v[i])
+                atomicAdd(&g_path_stats[i], (unsigned long long)ps.v[i]);
+    }
+#endif
     if (!valid)
         return;
 
@@ -239,12 +269,12 @@ __global__ __launch_bounds__(256, C <= 3 ? 7 : 1) void mog2_frames_kernel(const 
         if (m < nmodes) {
             float *pm = planes_ + (size_t)m * F * np;
             if (m > 0 || w0_dirty)
-                pm[rowoff + xl] = M.w[m];
-            store_mode_vec<C>(pm, np, rowoff + xl, M.var[m], M.mu[m]);
+                row_store<float>(pm + rowoff, xl * 4u, M.w[m]);
+            store_mode_vec_row<C>(pm, np, rowoff, xl, M.var[m], M.mu[m]);
         }
     }
     if (nm_dirty)
-        a.modes[rowoff + xl] = (uint8_t)mbyte;
+        row_store<uint8_t>(mrow_modes, xl, (uint8_t)mbyte);
 }
 
 }  // namespace
@@ -258,7 +288,7 @@ hipError_t mog2_frames_launch(const uint8_t *frame, uint8_t *mask, const Mog2Sta
 {
     if (n_img < 1 || h < 1 || w < 2 || T < 2 || T > kMaxT || (h + TH - 1) / TH > 65535 || n_img > 65535 ||
         st.np < (size_t)n_img * h * w || t.nkx != 3 || t.nky != 3 || t.kx[0] + t.kx[2] > 255 ||
-        t.kx[1] > 255 || t.ky[0] != t.ky[2])
+        t.kx[1] > 255 || t.ky[0] != t.ky[2] || !(k.var_min <= k.var_max))
         return hipErrorInvalidValue;
     Mog2FramesArgs a;
     a.frame = frame;
@@ -285,5 +315,19 @@ hipError_t mog2_frames_launch(const uint8_t *frame, uint8_t *mask, const Mog2Sta
     }
     return hipGetLastError();
 }
+
+#ifdef GOF_PATH_STATS
+// (stats builds only) read and clear the counters: out[32]
+extern "C" int gof_debug_path_stats(unsigned long long *out)
+{
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess)
+        e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_path_stats), 32 * sizeof(unsigned long long));
+    unsigned long long z[32] = {0};
+    if (e == hipSuccess)
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_path_stats), z, sizeof z);
+    return (int)e;
+}
+#endif
 
 }  // namespace gofk
