@@ -28,26 +28,26 @@ the MAX over ranks); every rank steps its own streams -- the path shards by
 stream with no data-path collective ("weak" scaling).
 
 Prints ONE JSON line on rank 0, with
-  roofline      -- the dominant kernel (fused blur + MOG2) against the roofline that
-                   bounds it.  8 frames per launch: vector-instruction issue (the
-                   model crosses HBM once per 8 frames, so memory is out of the way):
-                   achieved = SQ_INSTS_VALU / t (from the committed PMC pass of this
-                   configuration), peak = 1024 SIMDs x 2.4 GHz / 2 cycles (a SIMD-32
-                   takes two cycles per wave64 instruction: the 157 TFLOP/s fp32 rate);
-                   `cycles_per_valu_inst` next to it is what the mix of this kernel
-                   (64-bit encodings: v_dot4, v_mad_u32_u24, v_cndmask_e64 at 4.2-4.9
-                   cycles each, profiles/r01_valu_issue_rates.txt) actually costs;
-                   `hbm` = the launch's own algorithmic bytes / t against 8 TB/s.
-                   1 frame per launch: HBM (algorithmic bytes / t / 8 TB/s).
-                   Every frac is <= 1 by construction of its roofline.
+  roofline      -- the dominant kernel (fused blur + MOG2) against HBM: achieved = the launch's
+                   ALGORITHMIC bytes (frame in, mask out, live model read + written once
+                   per launch) / the kernel's average duration, measured here with HIP events on
+                   the launch stream (raw event time; the marker-corrected value sits beside it);
+                   peak 8 TB/s.  `traffic` = HBM bytes per launch from the committed rocprofv3 PMC
+                   passes of this same command (profiles/pmc_latest.json), `valu_issue` = what the
+                   8-frame launch is co-limited by (SQ_INSTS_VALU / t against 1024 SIMDs x 2.4 GHz /
+                   2 cycles).  Both come from a PMC record that carries the hash of the native
+                   sources it was taken from (pygofpid_amd/buildid.py): if it differs from this
+                   tree, `"pmc_stale": true` and everything derived from counters is null.
   per_frame     -- the same path with ONE frame per launch (what GOFPID.detect()
                    runs), whole-step timed by the same protocol + its kernel record
   detect_path   -- steps 1-3 + the GPU blob extraction of step 4 on every mask of a step
+  detect_host   -- GOFPID.detect() / detect_many() on host frames (PCIe-inclusive; never `value`)
   worst_case    -- reference-test style input (i.i.d. uniform uint8 frames,
                    /root/reference/tests/test_pipeline.py:98-109): every pixel carries
                    all 5 modes (206 B/px/frame), nothing is ever "settled"
-  cpu_baseline  -- the CPU oracle ("port" of the OpenCV algorithms, NOT OpenCV)
-                   timed on this host's cores on a bounded sample
+  cpu_baseline  -- the CPU oracle ("port" of the OpenCV algorithms, NOT OpenCV) timed on this
+                   host's cores on a bounded sample, started from the model state the GPU leg
+                   runs at (so both legs see the same mean mode count)
 """
 import argparse
 import json
@@ -111,10 +111,13 @@ def make_noise_pool(torch, streams, pool, h, w, device, seed):
                          dtype=torch.uint8)
 
 
-def cpu_baseline(frames_host, h, w, budget_s):
+def cpu_baseline(frames_host, h, w, budget_s, state=None, nframes=0, start=0):
     """Time the CPU oracle on this host (checker reused as the baseline leg).
     The thread count is the best of a short sweep up to the CPUs this process
-    may use; `cores` reports the count actually used for the timed sample."""
+    may use; `cores` reports the count actually used for the timed sample.
+    state / nframes: the trained model (SoA planes of ONE stream) and frame count the
+    run starts from -- the state of the GPU leg, so that both see the same clip state;
+    start: index of the next frame of the pool."""
     from oracle import cpu as oracle
     oracle.build()
     n = len(frames_host)
@@ -123,39 +126,49 @@ def cpu_baseline(frames_host, h, w, budget_s):
 
     def rate(threads, seconds, warm):
         p = oracle.Pipeline(h, w, 3, threads=threads)
-        for i in range(warm):
-            p.apply(frames_host[i % n])
+        if state is not None:
+            p.import_state(state, nframes)
+        k = start
+        for _ in range(warm):
+            p.apply(frames_host[k % n])
+            k += 1
+        m0 = p.mean_modes()
         done, t0 = 0, time.perf_counter()
         while True:
-            p.apply(frames_host[done % n])
+            p.apply(frames_host[k % n])
+            k += 1
             done += 1
             el = time.perf_counter() - t0
             if el >= seconds or done >= 4096:
-                return done / el, done, el, p
+                return done / el, done, el, p, m0
 
     best = max(cands, key=lambda t: rate(t, 0.6, 4)[0]) if len(cands) > 1 else cands[0]
-    fps, done, el, p = rate(best, budget_s, 8)
+    fps, done, el, p, m0 = rate(best, budget_s, 8)
     return {"value": round(fps, 2), "unit": "frames/s", "cores": best, "kind": "port",
-            "sample": "%d frames of 1 stream %dx%d BGR in %.1f s, OpenMP row bands over %d threads "
+            "sample": "%d frames of 1 stream %dx%d BGR (the %d-frame pool, continued from the model state "
+                      "and pool position of the GPU leg) in %.1f s, OpenMP row bands over %d threads "
                       "(best of %s on a %d-CPU budget); OpenCV-algorithm CPU restatement "
-                      "(oracle/gof_oracle.c), not OpenCV" % (done, w, h, el, best, cands, budget),
-            "mean_modes": round(p.mean_modes(), 4)}
+                      "(oracle/gof_oracle.c), not OpenCV" % (done, w, h, n, el, best, cands, budget),
+            "mean_modes": round(0.5 * (m0 + p.mean_modes()), 4)}
 
 
 def load_pmc(path, key):
     """The committed PMC record (profiles/) of this configuration, or {}: HBM bytes
     per launch (FETCH_SIZE x 2 + WRITE_SIZE, the gfx950 correction) and the SQ
     instruction counts per launch.  Counters cannot be read inside this process;
-    they come from separate `rocprofv3 --pmc` passes of this same command."""
+    they come from separate `rocprofv3 --pmc` passes of this same command.
+    -> (record, stale): stale when the record was taken from other native sources
+    than this tree's (pygofpid_amd/buildid.py) -- nothing may be derived from it then."""
+    from pygofpid_amd.buildid import build_id
     try:
         with open(path) as f:
             recs = json.load(f)
     except Exception:
-        return {}
+        return {}, True
     for rec in recs if isinstance(recs, list) else [recs]:
         if rec.get("config") == key:
-            return rec
-    return {}
+            return rec, rec.get("build_id") != build_id()
+    return {}, True
 
 
 class Runner:
@@ -252,42 +265,46 @@ def summarize_rounds(el, K, frames_per_step):
                          "max": round(max(el) * 1e3, 3)}}
 
 
-def kernel_record(pipe, mbar, T, kt, pmc, kernel_name):
-    """Roofline statement of one detector launch of T frames per stream (kt: Runner.kernel_times)."""
+def kernel_record(pipe, mbar, T, kt, pmc_and_stale, kernel_name):
+    """Roofline statement of one detector launch of T frames per stream (kt: Runner.kernel_times).
+    Primary time = the raw HIP-event mean; the marker-corrected mean is reported beside it."""
+    from pygofpid_amd.buildid import build_id
+    pmc, stale = pmc_and_stale
+    if stale:
+        pmc = dict(pmc, hbm_bytes_per_launch=None, sq_insts_valu=None)
     _, launch_b = pipe.algorithmic_bytes(mbar, T)
-    det_us, morph_us = kt["det_us"], kt["morph_us"]
+    det_us, morph_us = kt["det_raw_us"], kt["morph_raw_us"]
     t = det_us * 1e-6
+    hbm = launch_b / t / 1e9
+    traffic = pmc.get("hbm_bytes_per_launch")
     rec = {"kernel": kernel_name, "avg_kernel_us": round(det_us, 2), "launches_timed": kt["n"],
            "morph_kernel_us": round(morph_us, 2),
-           "event_timing": {"raw_avg_kernel_us": round(kt["det_raw_us"], 2),
+           "event_timing": {"what": "avg_kernel_us / morph_kernel_us are raw HIP-event means on the launch stream; "
+                                    "an event marker serialises the stream, the corrected values take the measured "
+                                    "marker cost off",
+                            "marker_corrected_kernel_us": round(kt["det_us"], 2),
+                            "marker_corrected_morph_us": round(kt["morph_us"], 2),
                             "raw_median_kernel_us": round(kt["det_median_raw_us"], 2),
-                            "raw_morph_kernel_us": round(kt["morph_raw_us"], 2),
                             "marker_overhead_us": round(kt["marker_us"], 2)},
            "mean_modes": round(mbar, 4),
            "algorithmic_bytes_per_launch": int(launch_b),
-           "traffic": pmc.get("hbm_bytes_per_launch")}
-    hbm = launch_b / t / 1e9
+           "bound": "hbm", "achieved": round(hbm, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": round(hbm / HBM_PEAK_GBS, 4),
+           "traffic": traffic,
+           "traffic_frac": round(traffic / t / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+           "build_id": build_id(), "pmc_build_id": pmc.get("build_id"), "pmc_stale": bool(stale),
+           "pmc_source": pmc.get("source")}
     if T > 1:
         insts = pmc.get("sq_insts_valu")
-        rec.update({
-            "bound": "valu-issue",
+        rec["valu_issue"] = {
+            "what": "the multi-frame launch is co-limited by vector-instruction issue: SQ_INSTS_VALU per launch "
+                    "(PMC pass) / t against %d SIMDs x %.1f GHz / %d cycles per wave64 instruction"
+                    % (N_SIMD, CLOCK_HZ / 1e9, VALU_ISSUE_CYCLES),
+            "valu_insts_per_launch": insts,
             "achieved": round(insts / t / 1e9, 1) if insts else None,
             "peak": round(VALU_PEAK_GINST, 1), "unit": "G wave-instr/s",
             "frac": round(insts / t / 1e9 / VALU_PEAK_GINST, 4) if insts else None,
-            "valu_insts_per_launch": insts,
-            "cycles_per_valu_inst": round(N_SIMD * CLOCK_HZ * t / insts, 2) if insts else None,
-            "valu_model": "achieved = SQ_INSTS_VALU per launch (committed PMC pass, %s) / t; peak = %d "
-                          "SIMDs x %.1f GHz / %d cycles per wave64 instruction; measured issue cost "
-                          "of this kernel's opcodes: 2.4 (32-bit encodings) to 4.9 (v_dot4) cycles"
-                          % (pmc.get("source", "-"), N_SIMD, CLOCK_HZ / 1e9, VALU_ISSUE_CYCLES),
-            "hbm": {"achieved": round(hbm, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(hbm / HBM_PEAK_GBS, 4),
-                    "traffic_frac": round(pmc["hbm_bytes_per_launch"] / t / 1e9 / HBM_PEAK_GBS, 4)
-                    if pmc.get("hbm_bytes_per_launch") else None},
-        })
-    else:
-        rec.update({"bound": "hbm", "achieved": round(hbm, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(hbm / HBM_PEAK_GBS, 4)})
+            "cycles_per_valu_inst": round(N_SIMD * CLOCK_HZ * t / insts, 2) if insts else None}
     return rec
 
 
@@ -377,6 +394,16 @@ def main():
     main_sum = summarize_rounds(el, K, S * T * world)
     mbar = 0.5 * (mbar_start + pipe.mean_modes())
     fg = float((masks[:T] != 0).float().mean().item())
+    # the CPU leg starts from here: model of stream 0, its frame count, the pool position
+    cpu_state = None
+    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+        run.sync()
+        st = pipe.mog2_state()
+        npx = h * w
+        cpu_state = ({"weight": st["weight"][:, :npx].copy(), "var": st["var"][:, :npx].copy(),
+                      "mean": st["mean"][:, :, :npx].copy(), "modes": st["modes"][:npx].copy()},
+                     int(st["nframes"]), (run.i * T) % frames.shape[0])
+        del st
 
     # 4: kernel times, outside the timed rounds
     kt = None
@@ -425,7 +452,7 @@ def main():
             roof = kernel_record(pipe, mbar, T, kt, load_pmc(args.pmc_file, key), name)
             _, per_frame_b = pipe.algorithmic_bytes(mbar, 1)
             det_us = kt["det_us"]
-            roof["kernels_us_per_step"] = round(kt["det_us"] + kt["morph_us"], 2)
+            roof["kernels_us_per_step"] = round(kt["det_us"] + kt["morph_us"], 2)   # (marker-corrected)
             roof["step_us"] = round(main_sum["ms_per_step"] * 1e3, 2)
             if T > 1:
                 # NOT a roofline: what one-frame-per-pass traffic (6 + 40 m B/px/frame)
@@ -532,9 +559,9 @@ def main():
         del nrun, npipe, nframes
 
     if rank == 0:
-        if args.cpu_seconds > 0 and world == 1:   # CPU leg: rank 0 at N = 1 only
-            host = [frames[i, 0].cpu().numpy() for i in range(min(32, frames.shape[0]))]
-            out["cpu_baseline"] = cpu_baseline(host, h, w, args.cpu_seconds)
+        if args.cpu_seconds > 0 and world == 1 and cpu_state is not None:   # CPU leg: rank 0 at N = 1 only
+            host = [frames[i, 0].cpu().numpy() for i in range(frames.shape[0])]
+            out["cpu_baseline"] = cpu_baseline(host, h, w, args.cpu_seconds, *cpu_state)
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)

@@ -105,6 +105,8 @@ def lib():
         L.gofo_mog2_nframes.argtypes = [C.c_void_p]
         L.gofo_mog2_nframes.restype = C.c_int
         L.gofo_mog2_export.argtypes = [C.c_void_p, _f32p, _f32p, _f32p, _u8p]
+        L.gofo_mog2_import.argtypes = [C.c_void_p, _f32p, _f32p, _f32p, _u8p, C.c_int]
+        L.gofo_mog2_import.restype = None
         L.gofo_mog2_apply.argtypes = [C.c_void_p, _u8p, _u8p]
         L.gofo_fd_apply.argtypes = [_u8p, _u8p, C.c_int, C.c_double, C.c_int, C.c_int,
                                     C.c_int, _u8p]
@@ -303,6 +305,23 @@ class Pipeline:
         lib().gofo_mog2_export(m, wt.ctypes.data_as(_f32p), var.ctypes.data_as(_f32p),
                                mean.ctypes.data_as(_f32p), _p8(modes))
         return {"weight": wt, "var": var, "mean": mean, "modes": modes}
+
+    def import_state(self, state, nframes):
+        """Start from a trained model: SoA planes as export() returns them (weight (K,N), var (K,N),
+        mean (K,C,N), modes (N,)) and the number of frames seen (it sets the learning rate)."""
+        m = lib().gofo_pipeline_mog2(self._h)
+        if not m:
+            raise ValueError("not a MOG2 pipeline")
+        h, w, c = self.shape
+        n, K = h * w, 5
+        wt = np.ascontiguousarray(state["weight"], np.float32)
+        var = np.ascontiguousarray(state["var"], np.float32)
+        mean = np.ascontiguousarray(state["mean"], np.float32)
+        modes = np.ascontiguousarray(state["modes"], np.uint8)
+        if wt.shape != (K, n) or var.shape != (K, n) or mean.shape != (K, c, n) or modes.shape != (n,):
+            raise ValueError("state planes do not match this pipeline's geometry")
+        lib().gofo_mog2_import(m, wt.ctypes.data_as(_f32p), var.ctypes.data_as(_f32p),
+                               mean.ctypes.data_as(_f32p), _p8(modes), int(nframes))
 
     def __del__(self):
         if getattr(self, "_h", None):

@@ -392,6 +392,26 @@ void gofo_mog2_export(const gofo_mog2 *m, float *weight, float *var, float *mean
     }
 }
 
+/* The inverse of gofo_mog2_export, plus the frame counter (which sets the learning rate): lets a
+ * timing run or a test start from a trained model (bench.py feeds the CPU leg the state the GPU
+ * leg runs at).  Planes as gofo_mog2_export writes them. */
+void gofo_mog2_import(gofo_mog2 *m, const float *weight, const float *var, const float *mean,
+                      const uint8_t *modes, int nframes)
+{
+    size_t n = (size_t)m->h * m->w;
+    int K = m->p.nmixtures, C = m->c;
+    for (size_t i = 0; i < n; i++) {
+        for (int k = 0; k < K; k++) {
+            m->gmm[i * K + k].weight = weight[(size_t)k * n + i];
+            m->gmm[i * K + k].variance = var[(size_t)k * n + i];
+            for (int ch = 0; ch < C; ch++)
+                m->mean[(i * K + k) * C + ch] = mean[((size_t)k * C + ch) * n + i];
+        }
+        m->modes[i] = modes[i];
+    }
+    m->nframes = nframes;
+}
+
 /* detectShadowGMM [OPENCV-RECALL]; runs on the model AFTER this frame's update. */
 static int shadow_gmm(const float *data, int nch, int nmodes, const gofo_gmm *gmm,
                       const float *mean, float Tb, float TB, float tau)

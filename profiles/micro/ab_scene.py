@@ -2,7 +2,7 @@
 """A/B of builds of libgofpid_hip.so on bench.py's scene (8 x 1080p, 256-frame pool, steady state):
 detector + morphology kernel time per 8-frame launch, HIP events on the launch stream.
 
-    python profiles/micro/ab_scene.py [name=path.so ...]      (no argument: the in-tree build)
+    python profiles/micro/ab_scene.py [name=path.so[@ENV=VALUE...] ...]      (no argument: the in-tree build)
 
 Each build runs in its own process (the library is chosen at import time); the builds are run
 round-robin, REPEAT (env, default 2) times each, so that box drift shows up as spread.
@@ -57,6 +57,10 @@ def main():
     for _ in range(rep):
         for name, path in builds:
             env = dict(os.environ, GOF_AB_CHILD="1")
+            path, *knobs = path.split("@")   # name=path@ENV=VALUE@...: environment knobs of this arm
+            for kv in knobs:
+                k, v = kv.split("=", 1)
+                env[k] = v
             if path:
                 env["GOFPID_LIB"] = os.path.abspath(path)
             out = subprocess.run([sys.executable, os.path.abspath(__file__)], env=env, capture_output=True, text=True)

@@ -15,6 +15,9 @@ import os
 import sys
 from collections import defaultdict
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pygofpid_amd.buildid import build_id  # noqa: E402  (hash of the native sources this run was built from)
+
 
 def rows(pattern):
     for path in glob.glob(pattern, recursive=True):
@@ -77,6 +80,7 @@ def main(d, fps, inp, timed, streams=8, h=1080, w=1920):
             write = cs["WRITE_SIZE"] * 1024.0
             rec = {"config": {"streams": streams, "height": h, "width": w, "frames_per_step": fps,
                               "input": inp},
+                   "build_id": build_id(),
                    "kernel": k, "fetch_size_raw_bytes": fetch_raw, "fetch_bytes_corrected": 2 * fetch_raw,
                    "write_bytes": write, "hbm_bytes_per_launch": 2 * fetch_raw + write,
                    "sq_insts_valu": cs.get("SQ_INSTS_VALU"), "sq_insts_salu": cs.get("SQ_INSTS_SALU"),

@@ -398,8 +398,11 @@ hipError_t mog2_apply(const uint8_t *frame, uint8_t *mask, const Mog2State &st, 
     // (its variance clamp is one v_med3_f32, which needs var_min <= var_max; anything else
     // takes the general kernel below)
     if (aln && T > 1 && w > 1 && t.kx[0] + t.kx[2] <= 255 && t.ky[0] == t.ky[2] &&
-        k.var_min <= k.var_max)   // the multi-frame launch proper
-        return mog2_frames_launch(frame, mask, st, n_img, h, w, c, T, k, t, s, rowflags);
+        k.var_min <= k.var_max) {   // the multi-frame launch proper
+        const hipError_t e = mog2_frames_launch(frame, mask, st, n_img, h, w, c, T, k, t, s, rowflags);
+        if (e != hipErrorNotSupported)
+            return e;
+    }
     // A/B knob of the LDS tile-size sweep (BASELINE config 3): rows per tile of the per-frame
     // BGR kernel, 2 | 4 | 8 (64 px wide, one wave per row)
     // Default 2: the sweep (profiles/r02_tile_sweep.txt) has 2 rows ahead of 4 and 8 at

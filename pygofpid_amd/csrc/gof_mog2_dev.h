@@ -593,16 +593,18 @@ __device__ __forceinline__ bool mog2_try_first_fits(PixelModel<C> &M, int &nmode
     M.w[0] = wstore;
     float totalWeight = 0.f + wstore;
     // m >= 1: decay, prune; the loop bound is the live mode count
+    int top = 1;   // wave-uniform: slots [0, top) were visited (what lies beyond a pixel's count is dead storage)
 #pragma unroll
     for (int m = 1; m < kMaxModes; m++) {
         if (__builtin_amdgcn_ballot_w64(m < nmodes) == 0)
             break;   // (no pixel of the wave has this slot; the later ones neither)
+        top = m + 1;
         const bool live = m < nmodes;
         const float wm = k.alpha1 * M.w[m] + k.prune;
         pruned = live && wm < negprune;
         wstore = pruned ? 0.f : wm;
         nmodes -= pruned ? 1 : 0;
-        M.w[m] = live ? wstore : M.w[m];
+        M.w[m] = wstore;
         totalWeight += live ? wstore : 0.f;
     }
     float inv = 0.f;
@@ -610,9 +612,9 @@ __device__ __forceinline__ bool mog2_try_first_fits(PixelModel<C> &M, int &nmode
         inv = div_normal(1.f, totalWeight);
 #pragma unroll
     for (int m = 0; m < kMaxModes; m++) {
-        if (m > 0 && __builtin_amdgcn_ballot_w64(m < nmodes) == 0)
+        if (m >= top)
             break;
-        M.w[m] = m < nmodes ? M.w[m] * inv : M.w[m];
+        M.w[m] *= inv;
     }
     nmodes_io = nmodes;
     return true;
@@ -780,6 +782,31 @@ struct FrameTiles {
 // 12-byte tap pattern: the horizontal pass of a row is then three v_dot4_u32_u8 per
 // channel on the three aligned dwords, nothing else.  xc: the lane's image column
 // (a lane outside the image passes the tile's first column).
+constexpr int kTapRow = 12;                  // dwords per row of the tap table (C <= 4 channels x 3)
+constexpr int kTapTableDwords = 12 * kTapRow;   // rows: (interior, first column, last column) x (pmin & 3)
+
+// TapPatterns::build on the host, for every (kind, start offset) a lane can have: byte rel[t] of the
+// 12-byte window carries tap t (taps that the border reflection folds onto one byte add up).
+inline void tap_table(uint32_t kxw, int C, uint32_t (&table)[kTapTableDwords])
+{
+    const uint32_t kx[3] = {kxw & 255u, (kxw >> 8) & 255u, (kxw >> 16) & 255u};
+    for (int kind = 0; kind < 3; kind++) {
+        for (int a = 0; a < 4; a++) {
+            // offsets of the left / centre / right pixel from the window's first dword
+            const int rel[3] = {kind == 1 ? a + C : a, kind == 1 ? a : a + C, kind == 0 ? a + 2 * C : (kind == 1 ? a + C : a)};
+            for (int c = 0; c < 4; c++) {
+                uint32_t bytes[16] = {0};
+                if (c < C)
+                    for (int t = 0; t < 3; t++)
+                        bytes[rel[t] + c] += kx[t];
+                for (int i = 0; i < 3 && c * 3 + i < kTapRow; i++)
+                    table[(kind * 4 + a) * kTapRow + c * 3 + i] =
+                        bytes[4 * i] | (bytes[4 * i + 1] << 8) | (bytes[4 * i + 2] << 16) | (bytes[4 * i + 3] << 24);
+            }
+        }
+    }
+}
+
 template <int C>
 struct TapPatterns {
     uint32_t pat[C][3];
@@ -816,6 +843,26 @@ struct TapPatterns {
         }
     }
 
+    // The same patterns from a table the launcher built (tap_table below): a lane's patterns
+    // depend only on where its window starts within a dword (pmin & 3) and on whether it sits on
+    // the image's first / last column -- 12 rows of kTapRow dwords, fetched with three loads
+    // instead of ~50 vector instructions of shifting per wave.  Needs W > 1.
+    __device__ __forceinline__ void load(int xc, int W, int sx0, int mis0,
+                                         const uint32_t __attribute__((address_space(4))) *table)
+    {
+        const bool left = xc == 0, right = xc == W - 1;
+        const int pc = (xc - sx0) * C + mis0;
+        const int pmin = left ? pc : pc - C;
+        A = pmin & ~3;
+        const uint32_t row = (left ? 4u : right ? 8u : 0u) + (uint32_t)(pmin & 3);
+        const uint32_t __attribute__((address_space(4))) *r = table + row * kTapRow;
+#pragma unroll
+        for (int c = 0; c < C; c++)
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+                pat[c][i] = r[c * 3 + i];
+    }
+
     // blurred pixel from the 3 x 3 aligned dwords at window address wa of a tile:
     // horizontal pass as dot products against the patterns, vertical pass as 24-bit
     // multiply-adds onto the rounding constant (`half`, 2^15 in a VGPR: the
@@ -841,19 +888,37 @@ struct TapPatterns {
         }
 #endif
         uint32_t win[3][3];
+        if (batch) {
+            // the nine reads back to back as single ds_read_b32 (the compiler pairs them into
+            // ds_read2_b32 and then spends four moves per frame untangling the register pairs);
+            // the window's LDS address = the tile array's LDS offset (0: it is the kernels' only
+            // LDS array) + wa
+            const uint32_t lds_wa = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint32_t *)tiles + wa;
+            asm volatile("ds_read_b32 %0, %9\n\t"
+                         "ds_read_b32 %1, %9 offset:4\n\t"
+                         "ds_read_b32 %2, %9 offset:8\n\t"
+                         "ds_read_b32 %3, %9 offset:%c10\n\t"
+                         "ds_read_b32 %4, %9 offset:%c11\n\t"
+                         "ds_read_b32 %5, %9 offset:%c12\n\t"
+                         "ds_read_b32 %6, %9 offset:%c13\n\t"
+                         "ds_read_b32 %7, %9 offset:%c14\n\t"
+                         "ds_read_b32 %8, %9 offset:%c15\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(win[0][0]), "=&v"(win[0][1]), "=&v"(win[0][2]), "=&v"(win[1][0]),
+                           "=&v"(win[1][1]), "=&v"(win[1][2]), "=&v"(win[2][0]), "=&v"(win[2][1]),
+                           "=&v"(win[2][2])
+                         : "v"(lds_wa), "n"(ROWD * 4), "n"(ROWD * 4 + 4), "n"(ROWD * 4 + 8), "n"(ROWD * 8),
+                           "n"(ROWD * 8 + 4), "n"(ROWD * 8 + 8)
+                         : "memory");
+        } else {
 #pragma unroll
-        for (int j = 0; j < 3; j++) {
-            const uint32_t *q = (const uint32_t *)((const char *)tiles + wa + (uint32_t)(j * ROWD) * 4u);
+            for (int j = 0; j < 3; j++) {
+                const uint32_t *q = (const uint32_t *)((const char *)tiles + wa + (uint32_t)(j * ROWD) * 4u);
 #pragma unroll
-            for (int i = 0; i < 3; i++)
-                win[j][i] = q[i];
+                for (int i = 0; i < 3; i++)
+                    win[j][i] = q[i];
+            }
         }
-        // keeps all nine live at one point: the reads are issued back to back
-        if (batch)
-            asm volatile(""
-                         : "+v"(win[0][0]), "+v"(win[0][1]), "+v"(win[0][2]), "+v"(win[1][0]),
-                           "+v"(win[1][1]), "+v"(win[1][2]), "+v"(win[2][0]), "+v"(win[2][1]),
-                           "+v"(win[2][2]));
 #pragma unroll
         for (int c = 0; c < C; c++) {
             // The vertical taps of a Gaussian are symmetric (ky[0] == ky[2]; the launcher
@@ -881,6 +946,7 @@ struct TapPatterns {
         }
     }
 };
+
 
 
 inline dim3 grid3(int w, int h, int n, int tw, int th)

@@ -43,6 +43,7 @@ struct Mog2FramesArgs {
     uint8_t *rowflags;   // [image][row][tile column] bytes, bit t = frame t's mask not all zero there (or NULL)
     int flag_pitch;
     Mog2Consts k;
+    uint32_t taps[kTapTableDwords];   // tap_table(kxw, C): the lanes' blur patterns
 };
 
 // (7 waves per SIMD for BGR: the issue-bound launch needs every one of them; the float4
@@ -61,8 +62,13 @@ __global__ __launch_bounds__(256, C <= 3 ? GOF_FRAMES_WAVES : 1) void mog2_frame
     const int H = a.H, W = a.W, T = a.T;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
-    const int img = blockIdx.z;
+    // (An XCD-aware workgroup -> tile mapping -- runs of q tiles per XCD, q = 2 .. 480, or one
+    // contiguous eighth of the tiles each -- was measured again in round 3 on this kernel: 0 to
+    // +3 % time for every q although it removes the re-fetch of halo rows and shared lines between
+    // tiles; profiles/r03_xcd_mapping.txt.  The plain grid stays.)
+    const int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    const int x0 = bx * TW, y0 = by * TH;
+    const int img = bz;
     const int x = x0 + lane, y = y0 + wave;
     const size_t N = (size_t)H * W;
 
@@ -89,6 +95,13 @@ __global__ __launch_bounds__(256, C <= 3 ? GOF_FRAMES_WAVES : 1) void mog2_frame
     if (__builtin_amdgcn_ballot_w64(!(mbyte_in & kW0One)) != 0)
         M.w[0] = row_load<float>(prow, xl * 4u);
     const uint32_t w0_in = __float_as_uint(M.w[0]);
+    // lane-invariant tap patterns (three loads from the launcher's table, issued with the model
+    // loads); a lane outside the image shadows the tile's first pixel
+    TapPatterns<C> taps;
+    {
+        typedef const Mog2FramesArgs __attribute__((address_space(4))) *ArgsPtr0;
+        taps.load(valid ? x : x0, W, ft.sx0, ft.mis0, ((ArgsPtr0)__builtin_amdgcn_kernarg_segment_ptr())->taps);
+    }
     // slots 1.. are loaded only if some pixel of the wave has them; otherwise slot 1
     // starts empty (the single-mode loops may fill it) and slots 2.. stay untouched
     // until the general loop is entered
@@ -97,9 +110,12 @@ __global__ __launch_bounds__(256, C <= 3 ? GOF_FRAMES_WAVES : 1) void mog2_frame
     Tiles::store(tiles, wave, lane, raw);
     const bool multi_in = __builtin_amdgcn_ballot_w64(nmodes > 1) != 0;
     if (multi_in) {
+        // slot m is fetched by the whole wave if any of its pixels has it (the lines travel anyway;
+        // what a pixel without the slot gets is dead storage, see mog2_update): no per-lane test,
+        // no zero fill
 #pragma unroll
         for (int m = 1; m < kMaxModes; m++) {
-            if (m < nmodes) {
+            if (__builtin_amdgcn_ballot_w64(m < nmodes) != 0) {
                 const float *pm = planes_ + (size_t)m * F * np;
                 M.w[m] = row_load<float>(pm + rowoff, xl * 4u);
                 load_mode_vec_row<C>(pm, np, rowoff, xl, M.var[m], M.mu[m]);
@@ -118,18 +134,16 @@ __global__ __launch_bounds__(256, C <= 3 ? GOF_FRAMES_WAVES : 1) void mog2_frame
         for (int c = 0; c < C; c++)
             M.mu[1][c] = 0.f;
     }
+    // The only barrier, as soon as this wave's tile rows are in LDS.  It orders LDS only (the
+    // model loads above stay in flight across it: __syncthreads() would wait for them, and a
+    // settled wave would then sit out the second round trip of a neighbour that fetches five modes).
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
-
-    // lane-invariant tap patterns; a lane outside the image shadows the tile's first pixel
-    TapPatterns<C> taps;
-    taps.build(valid ? x : x0, W, ft.sx0, ft.mis0, a.kxw);
     uint32_t wa = (uint32_t)(wave * ROWD) * 4u + (uint32_t)taps.A;   // window address, current frame
     uint32_t half = 32768u;
     float var_max_v = a.k.var_max;   // (the clamp takes one scalar operand, var_min)
     asm volatile("" : "+v"(half), "+v"(var_max_v));   // kept in registers, not re-materialised per use
     const uint32_t ky[3] = {a.ky012 & 1023u, (a.ky012 >> 10) & 1023u, a.ky012 >> 20};
-
-    __syncthreads();   // the only barrier: every tile is in LDS
 
     // blurred pixel of the current frame as floats (batch: the nine LDS reads issued
     // back to back -- not in the general loop, which has the whole mixture in registers)
@@ -248,7 +262,7 @@ __global__ __launch_bounds__(256, C <= 3 ? GOF_FRAMES_WAVES : 1) void mog2_frame
     // one flag byte per wave and launch for the morphology that follows (the settled
     // loop only ever writes zeros, so it contributes no bits)
     if (a.rowflags != nullptr && y < H && lane == 0)
-        a.rowflags[((size_t)img * H + y) * a.flag_pitch + blockIdx.x] = (uint8_t)nz;
+        a.rowflags[((size_t)img * H + y) * a.flag_pitch + bx] = (uint8_t)nz;
 #ifdef GOF_PATH_STATS
     if (lane == 0 && y < H) {
 #pragma unroll
@@ -306,6 +320,7 @@ hipError_t mog2_frames_launch(const uint8_t *frame, uint8_t *mask, const Mog2Sta
     a.rowflags = rowflags;
     a.flag_pitch = rowflag_pitch(w);
     a.k = k;
+    tap_table(a.kxw, c, a.taps);
     const dim3 g = grid3(w, h, n_img, TW, TH);
     switch (c) {
     case 1: hipLaunchKernelGGL(mog2_frames_kernel<1>, g, dim3(256), 0, s, a); break;
