@@ -527,6 +527,48 @@ def main():
         }
         del ex
 
+    # the drop-in API on host frames: GOFPID.detect() / detect_many() (pygofpid/pipeline.py:434-493),
+    # PCIe-inclusive -- reported beside the kernels, never as `value`
+    if not args.no_extra and not args.noise and world == 1 and not args.no_events:
+        from pygofpid_amd.pipeline import GOFPID
+        host = [frames[i, 0].cpu().numpy() for i in range(frames.shape[0])]
+        nb = host[0].nbytes
+        # what the link gives for one frame from the same (pageable) buffers
+        dst = torch.empty(nb, dtype=torch.uint8, device=device)
+        srcs = [torch.from_numpy(f.reshape(-1)) for f in host[:16]]
+        for k in range(8):
+            dst.copy_(srcs[k], non_blocking=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(64):
+            dst.copy_(srcs[k % 16], non_blocking=True)
+        torch.cuda.synchronize()
+        h2d = nb * 64 / (time.perf_counter() - t0) / 1e9
+        g = GOFPID().initialize()
+        g.detect_many(host)                                  # trains the model on one pass of the pool
+        n1, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < 1.0:
+            g.detect(host[n1 % len(host)])
+            n1 += 1
+        r1 = n1 / (time.perf_counter() - t0)
+        nm, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < 1.5:
+            g.detect_many(host[:64] if nm % 128 == 0 else host[64:128])
+            nm += 64
+        rm = nm / (time.perf_counter() - t0)
+        out["detect_host"] = {
+            "what": "GOFPID on host frames (one 1080p BGR stream, pageable numpy buffers): upload, steps 1-3 and the "
+                    "blob extraction on the GPU, blob records down, steps 5-7 on the host (Python); detect_many "
+                    "pipelines batches of 8 frames (upload of batch k + 1 beside the kernels of batch k and the host "
+                    "steps of batch k)",
+            "detect_frames_per_s": round(r1, 1), "detect_many_frames_per_s": round(rm, 1),
+            "bytes_up_per_frame": nb,
+            "h2d_GBps_measured": round(h2d, 1), "h2d_bound_frames_per_s": round(h2d * 1e9 / nb, 1),
+            "detect_many_h2d_GBps": round(rm * nb / 1e9, 1),
+            "detect_many_frac_of_h2d": round(rm * nb / 1e9 / h2d, 3),
+            "detect_frac_of_h2d": round(r1 * nb / 1e9 / h2d, 3)}
+        del g, host, srcs, dst
+
     # worst case: uniform-noise input, every pixel carries all five modes
     if not args.no_extra and not args.noise and world == 1 and not args.no_events:
         del run, pipe

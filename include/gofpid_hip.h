@@ -50,7 +50,7 @@ extern "C" {
 /* 2: blob extraction (gof_blobs_*), gof_pipeline_set_convert, per-apply profile series; the
  *    device layout behind gof_mog2_device_state / state_copy changed (a model buffer of
  *    version 1 must not be copied into a version 2 library: re-export / import instead) */
-#define GOF_ABI_VERSION 2
+#define GOF_ABI_VERSION 3
 
 enum {
     GOF_OK = 0,
@@ -280,7 +280,22 @@ int gof_pipeline_apply_host_blobs(gof_pipeline *p, const uint8_t *frames, int n_
  * no host-side gathering copy (a video reader hands out one array per frame) */
 int gof_pipeline_apply_host_blobs_ptrs(gof_pipeline *p, const uint8_t *const *frames, int n_frames,
                                        gof_blobs *b, double min_area);
+/* The same, asynchronously, for a caller that pipelines batches (GOFPID.detect_many: the frames of
+ * batch k + 1 go up while the kernels of batch k run and the host works on the records of batch k):
+ * enqueue a batch into slot 0 or 1 -- returns once the frames have left the caller's buffers (the
+ * upload runs on a copy stream of the library beside the kernels of the batch submitted before);
+ * steps 1-3 and the extraction into b are enqueued behind it, not waited for.  Batches must be
+ * submitted in stream order by one thread at a time, alternating slots, each slot with a gof_blobs
+ * of its own; gof_pipeline_wait_slot may be called from another thread.  Replaces nothing in the
+ * reference (its detect() is one synchronous frame, pygofpid/pipeline.py:434-493). */
+int gof_pipeline_submit_host_blobs_ptrs(gof_pipeline *p, const uint8_t *const *frames, int n_frames,
+                                        gof_blobs *b, double min_area, int slot);
+/* Wait for the batch submitted into the slot: its records are then in its gof_blobs (and
+ * gof_pipeline_fetch_masks returns the masks of the batch submitted last). */
+int gof_pipeline_wait_slot(gof_pipeline *p, int slot);
 int gof_pipeline_fetch_masks(gof_pipeline *p, uint8_t *masks, int n_frames);
+/* ... of the batch that went through the given slot last */
+int gof_pipeline_fetch_masks_slot(gof_pipeline *p, uint8_t *masks, int n_frames, int slot);
 
 /* Per-kernel timing with HIP events on the launch stream (what bench.py's
  * roofline block is computed from).  enable != 0: every following apply

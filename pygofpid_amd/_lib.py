@@ -131,6 +131,10 @@ SIGNATURES = {
     "gof_pipeline_apply_host_blobs_ptrs": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_void_p,
                                                      C.c_double]),
     "gof_pipeline_fetch_masks": (C.c_int, [C.c_void_p, _u8p, C.c_int]),
+    "gof_pipeline_fetch_masks_slot": (C.c_int, [C.c_void_p, _u8p, C.c_int, C.c_int]),
+    "gof_pipeline_submit_host_blobs_ptrs": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_void_p,
+                                                      C.c_double, C.c_int]),
+    "gof_pipeline_wait_slot": (C.c_int, [C.c_void_p, C.c_int]),
     "gof_pipeline_profile_enable": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "gof_pipeline_profile_stride": (C.c_int, [C.c_void_p, C.c_int]),
     "gof_pipeline_profile_query": (C.c_int, [C.c_void_p, C.POINTER(C.c_double),

@@ -64,6 +64,14 @@ class BlobExtractor:
         lib = _lib.load()
         _lib.check(lib.gof_blobs_counts(self._h, int(image), C.byref(nb), C.byref(npts), C.byref(fl)))
         self.last_flags = fl.value
+        if fl.value & 8:
+            # GOF_BLOBS_INTERNAL: a bounded device loop ran out -- a bug, not an overflow.  The
+            # caller's fall-back (the host follower on the mask) still gives the right contours,
+            # but this must not pass silently as a slow frame.
+            import warnings
+            self.internal_faults = getattr(self, "internal_faults", 0) + 1
+            warnings.warn("gof_blobs: internal fault flag on image %d (flags %#x); falling back to the host "
+                          "contour path -- please report" % (image, fl.value), RuntimeWarning, stacklevel=2)
         if fl.value:
             return None
         recs = np.zeros(nb.value, RECORD_DTYPE)
@@ -104,6 +112,21 @@ def bottom_and_center(rec, dtype=np.int16):
     x = int(m["m10"] / m["m00"])
     return (np.array([x, int(rec["ymax"])], dtype=dtype),
             np.array([x, int(m["m01"] / m["m00"])], dtype=dtype))
+
+
+def bottoms_and_centers(records, dtype=np.int16):
+    """bottom_and_center for all records at once: (n, 2) arrays of (x, y); the same float64
+    quotients truncated toward zero, element for element."""
+    if len(records) == 0:
+        z = np.zeros((0, 2), dtype)
+        return z, z
+    a00 = records["a00"].astype(np.float64)
+    s = np.where(records["a00"] < 0, -1.0, 1.0)
+    m00, m10, m01 = s * a00 / 2.0, s * records["a10"].astype(np.float64) / 6.0, s * records["a01"].astype(np.float64) / 6.0
+    x = (m10 / m00).astype(np.int64)
+    cy = (m01 / m00).astype(np.int64)
+    return (np.stack([x, records["ymax"].astype(np.int64)], 1).astype(dtype),
+            np.stack([x, cy], 1).astype(dtype))
 
 
 def host_result(mask, min_area=100.0):

@@ -122,6 +122,14 @@ struct gof_pipeline {
     gof_mog2 *mog2 = nullptr;
     gof_fd *fd = nullptr;
     DevBuf in, out, blurred, m0, m1;
+    // Host-frame batches are double-buffered (slot 0 = in / out, slot 1 = in1 / out1): the frames
+    // of one batch go up on a copy stream while the kernels of the batch before run on the
+    // context's stream (gof_pipeline_submit_host_blobs_ptrs / gof_pipeline_wait_slot).
+    DevBuf in1, out1;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};
+    gof_blobs *slot_blobs[2] = {nullptr, nullptr};
+    int last_slot = 0;         // the slot whose `out` holds the masks of the last host batch
     DevBuf gray;       // step 0 (gof_pipeline_set_convert): the converted frames
     int cvt_c = 0;     // channels of the incoming frames when the conversion is on (else 0)
     bool cvt_rgb = false;
@@ -1213,8 +1221,18 @@ void gof_pipeline_destroy(gof_pipeline *p)
     (void)hipStreamSynchronize(p->ctx->stream);
     gof_mog2_destroy(p->mog2);
     gof_fd_destroy(p->fd);
+    if (p->copy_stream) {
+        (void)hipStreamSynchronize(p->copy_stream);
+        (void)hipStreamDestroy(p->copy_stream);
+    }
+    for (int i = 0; i < 2; i++)
+        for (hipEvent_t e : {p->ev_up[i], p->ev_free[i], p->ev_done[i]})
+            if (e)
+                (void)hipEventDestroy(e);
     p->in.release();
     p->out.release();
+    p->in1.release();
+    p->out1.release();
     p->blurred.release();
     p->m0.release();
     p->m1.release();
@@ -1417,6 +1435,7 @@ int gof_pipeline_apply_host_many(gof_pipeline *p, const uint8_t *frames, uint8_t
         return rc;
     GOF_HIP(hipMemcpyAsync(masks, p->out.p, npx, hipMemcpyDeviceToHost, s));
     GOF_HIP(hipStreamSynchronize(s));
+    p->last_slot = 0;
     return GOF_OK;
 }
 
@@ -1425,74 +1444,119 @@ int gof_pipeline_apply_host(gof_pipeline *p, const uint8_t *frames, uint8_t *mas
     return gof_pipeline_apply_host_many(p, frames, masks, 1);
 }
 
-int gof_pipeline_apply_host_blobs(gof_pipeline *p, const uint8_t *frames, int n_frames, gof_blobs *b,
-                                  double min_area)
+// One host batch into a slot: upload on the copy stream (from pageable memory this call blocks
+// until the frames have left the caller's buffers -- while the context's stream runs the kernels
+// of the batch submitted before), then steps 1-3 and the blob extraction enqueued behind it.
+static int submit_host_blobs(gof_pipeline *p, const uint8_t *const *frames, const uint8_t *packed, int n_frames,
+                             gof_blobs *b, double min_area, int slot)
 {
-    if (!p || !frames || !b)
+    if (!p || !b || (!frames && !packed))
         return fail(GOF_EINVAL, "NULL argument");
+    if (slot != 0 && slot != 1)
+        return fail(GOF_EINVAL, "slot must be 0 or 1, got %d", slot);
     if (n_frames < 1 || n_frames > 4096)
         return fail(GOF_EINVAL, "n_frames must be in [1, 4096], got %d", n_frames);
     if (b->ctx != p->ctx || b->h != p->d.h || b->w != p->d.w || b->n_img < n_frames * p->d.streams)
         return fail(GOF_EINVAL, "blob scratch (%d images of %dx%d) does not fit %d frames of %d streams of %dx%d",
                     b->n_img, b->h, b->w, n_frames, p->d.streams, p->d.h, p->d.w);
+    if (frames)
+        for (int i = 0; i < n_frames; i++)
+            if (!frames[i])
+                return fail(GOF_EINVAL, "frames[%d] is NULL", i);
     GOF_HIP(hipSetDevice(p->ctx->device));
     hipStream_t s = p->ctx->stream;
-    const size_t npx = (size_t)n_frames * p->d.streams * p->d.h * p->d.w;
-    const size_t cin = (size_t)in_channels(p);
+    if (!p->copy_stream) {
+        GOF_HIP(hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking));
+        for (int i = 0; i < 2; i++) {
+            GOF_HIP(hipEventCreateWithFlags(&p->ev_up[i], hipEventDisableTiming));
+            GOF_HIP(hipEventCreateWithFlags(&p->ev_free[i], hipEventDisableTiming));
+            GOF_HIP(hipEventCreateWithFlags(&p->ev_done[i], hipEventDisableTiming));
+        }
+    }
+    DevBuf &in = slot ? p->in1 : p->in, &out = slot ? p->out1 : p->out;
+    const size_t per = (size_t)p->d.streams * p->d.h * p->d.w, cin = (size_t)in_channels(p);
+    // the slot's buffers are free once the batch that used them last has been through its kernels
+    // (and its caller has had its records: a slot is waited for before it is submitted again)
+    if (p->slot_blobs[slot]) {
+        GOF_HIP(hipEventSynchronize(p->ev_done[slot]));
+        p->slot_blobs[slot]->pending = false;
+        p->slot_blobs[slot] = nullptr;
+    }
     int rc;
-    if ((rc = p->in.reserve(npx * cin)) || (rc = p->out.reserve(npx)))
+    if ((rc = in.reserve((size_t)n_frames * per * cin)) || (rc = out.reserve((size_t)n_frames * per)))
         return rc;
-    GOF_HIP(hipMemcpyAsync(p->in.p, frames, npx * cin, hipMemcpyHostToDevice, s));
-    if ((rc = gof_pipeline_apply_dev_many(p, p->in.p, p->out.p, n_frames, nullptr)))
+    if (packed) {
+        GOF_HIP(hipMemcpyAsync(in.p, packed, (size_t)n_frames * per * cin, hipMemcpyHostToDevice, p->copy_stream));
+    } else {
+        for (int i = 0; i < n_frames; i++)
+            GOF_HIP(hipMemcpyAsync((uint8_t *)in.p + (size_t)i * per * cin, frames[i], per * cin,
+                                   hipMemcpyHostToDevice, p->copy_stream));
+    }
+    GOF_HIP(hipEventRecord(p->ev_up[slot], p->copy_stream));
+    GOF_HIP(hipStreamWaitEvent(s, p->ev_up[slot], 0));
+    if ((rc = gof_pipeline_apply_dev_many(p, in.p, out.p, n_frames, nullptr)))
         return rc;
-    if ((rc = gof_blobs_extract_dev(b, p->out.p, n_frames * p->d.streams, min_area, nullptr)))
+    if ((rc = gof_blobs_extract_dev(b, out.p, n_frames * p->d.streams, min_area, nullptr)))
         return rc;
-    GOF_HIP(hipStreamSynchronize(s));
-    b->pending = false;
+    GOF_HIP(hipEventRecord(p->ev_done[slot], s));
+    p->slot_blobs[slot] = b;
+    p->last_slot = slot;
     return GOF_OK;
+}
+
+int gof_pipeline_submit_host_blobs_ptrs(gof_pipeline *p, const uint8_t *const *frames, int n_frames,
+                                        gof_blobs *b, double min_area, int slot)
+{
+    if (!frames)
+        return fail(GOF_EINVAL, "NULL argument");
+    return submit_host_blobs(p, frames, nullptr, n_frames, b, min_area, slot);
+}
+
+int gof_pipeline_wait_slot(gof_pipeline *p, int slot)
+{
+    if (!p || (slot != 0 && slot != 1))
+        return fail(GOF_EINVAL, "bad argument");
+    if (!p->slot_blobs[slot])
+        return GOF_OK;   // nothing in flight there
+    GOF_HIP(hipSetDevice(p->ctx->device));
+    GOF_HIP(hipEventSynchronize(p->ev_done[slot]));
+    p->slot_blobs[slot]->pending = false;
+    p->slot_blobs[slot] = nullptr;
+    return GOF_OK;
+}
+
+int gof_pipeline_apply_host_blobs(gof_pipeline *p, const uint8_t *frames, int n_frames, gof_blobs *b,
+                                  double min_area)
+{
+    if (!frames)
+        return fail(GOF_EINVAL, "NULL argument");
+    int rc = submit_host_blobs(p, nullptr, frames, n_frames, b, min_area, 0);
+    return rc ? rc : gof_pipeline_wait_slot(p, 0);
 }
 
 int gof_pipeline_apply_host_blobs_ptrs(gof_pipeline *p, const uint8_t *const *frames, int n_frames,
                                        gof_blobs *b, double min_area)
 {
-    if (!p || !frames || !b)
-        return fail(GOF_EINVAL, "NULL argument");
-    if (n_frames < 1 || n_frames > 4096)
-        return fail(GOF_EINVAL, "n_frames must be in [1, 4096], got %d", n_frames);
-    if (b->ctx != p->ctx || b->h != p->d.h || b->w != p->d.w || b->n_img < n_frames * p->d.streams)
-        return fail(GOF_EINVAL, "blob scratch (%d images of %dx%d) does not fit %d frames of %d streams of %dx%d",
-                    b->n_img, b->h, b->w, n_frames, p->d.streams, p->d.h, p->d.w);
-    for (int i = 0; i < n_frames; i++)
-        if (!frames[i])
-            return fail(GOF_EINVAL, "frames[%d] is NULL", i);
-    GOF_HIP(hipSetDevice(p->ctx->device));
-    hipStream_t s = p->ctx->stream;
-    const size_t per = (size_t)p->d.streams * p->d.h * p->d.w, cin = (size_t)in_channels(p);
-    int rc;
-    if ((rc = p->in.reserve((size_t)n_frames * per * cin)) || (rc = p->out.reserve((size_t)n_frames * per)))
-        return rc;
-    for (int i = 0; i < n_frames; i++)
-        GOF_HIP(hipMemcpyAsync((uint8_t *)p->in.p + (size_t)i * per * cin, frames[i], per * cin,
-                               hipMemcpyHostToDevice, s));
-    if ((rc = gof_pipeline_apply_dev_many(p, p->in.p, p->out.p, n_frames, nullptr)))
-        return rc;
-    if ((rc = gof_blobs_extract_dev(b, p->out.p, n_frames * p->d.streams, min_area, nullptr)))
-        return rc;
-    GOF_HIP(hipStreamSynchronize(s));
-    b->pending = false;
-    return GOF_OK;
+    int rc = gof_pipeline_submit_host_blobs_ptrs(p, frames, n_frames, b, min_area, 0);
+    return rc ? rc : gof_pipeline_wait_slot(p, 0);
 }
 
 int gof_pipeline_fetch_masks(gof_pipeline *p, uint8_t *masks, int n_frames)
 {
-    if (!p || !masks || n_frames < 1)
+    return gof_pipeline_fetch_masks_slot(p, masks, n_frames, p ? p->last_slot : 0);
+}
+
+int gof_pipeline_fetch_masks_slot(gof_pipeline *p, uint8_t *masks, int n_frames, int slot)
+{
+    if (!p || !masks || n_frames < 1 || (slot != 0 && slot != 1))
         return fail(GOF_EINVAL, "bad argument");
     const size_t npx = (size_t)n_frames * p->d.streams * p->d.h * p->d.w;
-    if (!p->out.p || p->out.cap < npx)
+    const DevBuf &out = slot ? p->out1 : p->out;
+    if (!out.p || out.cap < npx)
         return fail(GOF_EINVAL, "no masks of %d frame(s) on the device", n_frames);
     GOF_HIP(hipSetDevice(p->ctx->device));
     hipStream_t s = p->ctx->stream;
-    GOF_HIP(hipMemcpyAsync(masks, p->out.p, npx, hipMemcpyDeviceToHost, s));
+    GOF_HIP(hipMemcpyAsync(masks, out.p, npx, hipMemcpyDeviceToHost, s));
     GOF_HIP(hipStreamSynchronize(s));
     return GOF_OK;
 }

@@ -94,8 +94,8 @@ def broadcast_model(state, nframes, src=0):
 def warm_start(pipe, src=0):
     """Broadcast the model of `pipe` (a MOG2 ForegroundPipeline) from rank src.
 
-    Every rank must hold a pipeline of the same geometry and nmixtures: the sizes
-    are compared over the group first (a mismatch would hang or corrupt the
+    Every rank must hold a pipeline of the same geometry and nmixtures, built against the same
+    library ABI (the raw model layout is the library's): these are compared over the group first (a mismatch would hang or corrupt the
     broadcast) and ValueError is raised on every rank if they differ.  With one
     process this is a copy of the model through the staging buffer."""
     import torch
@@ -103,8 +103,10 @@ def warm_start(pipe, src=0):
     _, nbytes = pipe.mog2_device_state()
     dev = torch.device("cuda", pipe.device)
     if dist.is_available() and dist.is_initialized():
-        mine = torch.tensor([nbytes, pipe.streams, pipe.h, pipe.w, pipe.c, pipe.nmixtures],
-                            dtype=torch.int64, device=dev)
+        from . import _lib
+        # (the library's ABI version too: the raw model layout belongs to it)
+        mine = torch.tensor([nbytes, pipe.streams, pipe.h, pipe.w, pipe.c, pipe.nmixtures,
+                             _lib.load().gof_abi_version()], dtype=torch.int64, device=dev)
         every = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
         dist.all_gather(every, mine)
         if any(not torch.equal(e, every[src]) for e in every):

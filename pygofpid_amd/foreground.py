@@ -156,6 +156,42 @@ class ForegroundPipeline:
         self._last_T = T
         return [self._blobs.result(i) for i in range(T * self.streams)]
 
+    # -- pipelined batches (GOFPID.detect_many) ------------------------------
+    def submit_blobs_frames(self, frames, min_area=100.0, slot=0):
+        """apply_blobs_frames() without the wait: the frames go up (this call returns when they have
+        left their buffers) beside the kernels of the batch submitted into the other slot before;
+        wait_blobs(slot) returns the results.  Call it from one thread at a time, alternating slots."""
+        from .blobs import BlobExtractor
+        arrs = [_lib.as_u8(f, "frames") for f in frames]
+        per = self.streams * self.h * self.w * self.c
+        if not arrs or any(a.size != per for a in arrs):
+            raise ValueError("Input shape has changed.")
+        T = len(arrs)
+        if not hasattr(self, "_slot_blobs"):
+            self._slot_blobs, self._slot_T = [None, None], [0, 0]
+        ex = self._slot_blobs[slot]
+        if ex is None or ex.n_images < T * self.streams:
+            ex = self._slot_blobs[slot] = BlobExtractor(T * self.streams, self.h, self.w, ctx=self._ctx)
+        ptrs = (C.c_void_p * T)(*[a.ctypes.data for a in arrs])
+        _lib.check(_lib.load().gof_pipeline_submit_host_blobs_ptrs(self._h, ptrs, T, ex.handle,
+                                                                   float(min_area), int(slot)))
+        self._slot_T[slot] = T
+        return T
+
+    def wait_blobs(self, slot=0):
+        """Results of the batch submitted into `slot` (one (records, points) pair per mask, None
+        where the device scratch overflowed)."""
+        T = self._slot_T[slot]
+        _lib.check(_lib.load().gof_pipeline_wait_slot(self._h, int(slot)))
+        return [self._slot_blobs[slot].result(i) for i in range(T * self.streams)]
+
+    def slot_masks(self, slot=0):
+        """The masks of the batch that went through `slot` last, downloaded now: (T, streams, h, w)."""
+        T = self._slot_T[slot]
+        out = np.empty((T, self.streams, self.h, self.w), np.uint8)
+        _lib.check(_lib.load().gof_pipeline_fetch_masks_slot(self._h, _lib.p8(out), T, int(slot)))
+        return out
+
     def last_masks(self):
         """The masks of the last apply_blobs() call, downloaded now: (T, streams, h, w)."""
         T = getattr(self, "_last_T", 0)
@@ -263,8 +299,15 @@ class ForegroundPipeline:
             if "nmixtures" in z.files and int(z["nmixtures"]) != self.nmixtures:
                 raise ValueError("checkpoint has nmixtures=%d, this pipeline %d"
                                  % (int(z["nmixtures"]), self.nmixtures))
+            st = {k: z[k] for k in ("weight", "var", "mean", "modes")}
+            if "nmixtures" not in z.files:
+                # a checkpoint of the first format: planes padded to 5 modes, no nmixtures key --
+                # the modes this pipeline keeps are the first ones
+                K = self.nmixtures
+                if st["weight"].shape[0] >= K and st["mean"].shape[0] >= K and int(st["modes"].max(initial=0)) <= K:
+                    st.update(weight=st["weight"][:K], var=st["var"][:K], mean=st["mean"][:K])
             wt, var, mean, modes = _lib.mog2_state_arrays(
-                z, self.nmixtures, self.model_c, self.streams * self.h * self.w)
+                st, self.nmixtures, self.model_c, self.streams * self.h * self.w)
             _lib.check(_lib.load().gof_mog2_import(m, wt.ctypes.data_as(f32), var.ctypes.data_as(f32),
                                                    mean.ctypes.data_as(f32), _lib.p8(modes),
                                                    int(z["nframes"])))

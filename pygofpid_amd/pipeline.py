@@ -166,39 +166,56 @@ class GOFPID():
         self._post_filter()
         return self._maintain_alarm(self._detect_blob())
 
+    _CHUNK = 8   # frames per device batch of detect_many (the multi-frame kernels take 8 per launch)
+
     def detect_many(self, frames):
         """detect() on consecutive frames of the stream, in order: a list of its return values.
 
         Not in the reference; same results as calling detect() frame by frame (steps 4-7 never
-        feed back into steps 1-3).  On the fused path all frames go through ONE upload and the
-        multi-frame kernels (the background model crosses HBM once per 8 frames) and all their
-        blob records come back in one download; the host steps then run frame by frame.
+        feed back into steps 1-3).  On the fused path the frames go through the device in batches
+        of 8 (one upload from the frames' own buffers, the multi-frame kernels -- the background
+        model crosses HBM once per batch -- and one small download of all blob records), pipelined:
+        batch k + 1 is uploaded (by a helper thread, beside the kernels of batch k) while this
+        thread runs the host steps on the records of batch k.  Any number of frames; memory is
+        bounded by two batches.  All frames are validated before the first one is consumed.
         Attributes (`blobs_`, `tracked_blobs_`, `foreground_mask_`) are those of the last frame.
         """
         frames = [np.asarray(f) for f in frames]
+        shape = self.input_shape_ or (frames[0].shape if frames else None)
+        for f in frames:
+            if f.shape != shape:
+                raise ValueError('Input shape has changed.')
         out = []
         if frames and not getattr(self, '_fused_checked', False):
             out.append(self.detect(frames[0]))        # decides the path, calibrates on the shape
             frames = frames[1:]
         if self._fused is None or not frames:
             return out + [self.detect(f) for f in frames]
-        for f in frames:
-            if f.shape != self.input_shape_:
-                raise ValueError('Input shape has changed.')
-        results = self._fused.apply_blobs_frames(frames, min_area=self._AREA_MIN)
-        masks = None
-        for i, res in enumerate(results):
-            self._gpu_blobs = res
-            self._mask = None
-            self._mask_on_device = True
-            self._mask_index = i
-            if res is None:                           # device scratch overflow: this frame's mask, host path
-                masks = self._fused.last_masks() if masks is None else masks
-                self._mask = masks[i, 0]
-            self._find_blob()
-            self._track_blob()
-            self._post_filter()
-            out.append(self._maintain_alarm(self._detect_blob()))
+        if getattr(self, '_uploader', None) is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._uploader = ThreadPoolExecutor(max_workers=1, thread_name_prefix='gofpid-upload')
+        chunks = [frames[i:i + self._CHUNK] for i in range(0, len(frames), self._CHUNK)]
+        submit = self._fused.submit_blobs_frames
+        fut = self._uploader.submit(submit, chunks[0], self._AREA_MIN, 0)
+        for k in range(len(chunks)):
+            slot = k & 1
+            fut.result()                              # batch k is on the device (or raised)
+            if k + 1 < len(chunks):
+                fut = self._uploader.submit(submit, chunks[k + 1], self._AREA_MIN, slot ^ 1)
+            masks = None
+            for i, res in enumerate(self._fused.wait_blobs(slot)):
+                self._gpu_blobs = res
+                self._mask = None
+                self._mask_on_device = True
+                self._mask_index = i
+                self._mask_slot = slot
+                if res is None:                       # device scratch overflow: this frame's mask, host path
+                    masks = self._fused.slot_masks(slot) if masks is None else masks
+                    self._mask = masks[i, 0]
+                self._find_blob()
+                self._track_blob()
+                self._post_filter()
+                out.append(self._maintain_alarm(self._detect_blob()))
         return out
 
     def _fusable(self):
@@ -237,7 +254,9 @@ class GOFPID():
         """The final mask of the last frame.  On the fused path it lives on the device
         and is downloaded when (and only when) it is read."""
         if self._mask is None and self._mask_on_device:
-            self._mask = self._fused.last_masks()[self._mask_index, 0]
+            slot = getattr(self, '_mask_slot', None)
+            masks = self._fused.last_masks() if slot is None else self._fused.slot_masks(slot)
+            self._mask = masks[self._mask_index, 0]
         if self._mask is None:
             raise AttributeError("foreground_mask_")
         return self._mask
@@ -268,6 +287,7 @@ class GOFPID():
             self._mask = None
             self._mask_on_device = True
             self._mask_index = 0
+            self._mask_slot = None
             return
         # generic path: the reference's own call sequence
         if self.convert:
@@ -304,7 +324,7 @@ class GOFPID():
                              for key, val in samples.items()}
 
     def _predict_perspective(self, key, y):
-        y = np.clip(y, a_min=0, a_max=self.input_shape_[0] - 1)
+        y = min(max(int(y), 0), self.input_shape_[0] - 1)     # (np.clip of a scalar, without its overhead)
         return self._perspective.get(key)[y]
 
     # ----------------------------------------------------------------- blobs
@@ -312,12 +332,14 @@ class GOFPID():
         if self._gpu_blobs is not None and area_min == self._AREA_MIN:
             # contours, area filter and moments came from the device with the mask's header
             recs, pts = self._gpu_blobs
-            self.blobs_ = []
-            for rec, contour in zip(recs, gpublobs.contours_of(recs, pts)):
-                bottom, center = gpublobs.bottom_and_center(rec, dtype=np.int16)
-                anchor = bottom if self.post_filter['anchor'] == 'bottom' else center
-                self.blobs_.append({'contour': contour, 'anchor': anchor, 'bottom': bottom,
-                                    'center': center})
+            bottoms, centers = gpublobs.bottoms_and_centers(recs, dtype=np.int16)   # all records at once
+            use_bottom = self.post_filter['anchor'] == 'bottom'
+            self.blobs_ = [{'contour': contour, 'anchor': bottoms[i] if use_bottom else centers[i],
+                            'bottom': bottoms[i], 'center': centers[i],
+                            # (cv.boundingRect of the contour, from the record's extremes)
+                            'bbox': (int(r['xmin']), int(r['ymin']), int(r['xmax'] - r['xmin'] + 1),
+                                     int(r['ymax'] - r['ymin'] + 1))}
+                           for i, (r, contour) in enumerate(zip(recs, gpublobs.contours_of(recs, pts)))]
             return
         contours = [c for c in find_contours(self.foreground_mask_)
                     if hostcv.contourArea(c) >= area_min]
@@ -340,10 +362,7 @@ class GOFPID():
                 self._update_unpaired_tracked_blob(j)
             return
 
-        dist = np.zeros((n_blobs, n_tracked))
-        for i in range(n_blobs):
-            for j in range(n_tracked):
-                dist[i, j] = self._compute_tracking_distance(j, i)
+        dist = self._tracking_distances()
 
         for i in range(n_blobs):
             j_min = np.argmin(dist[i])
@@ -357,12 +376,24 @@ class GOFPID():
             if np.all(dist[:, j] >= 0):
                 self._update_unpaired_tracked_blob(j)
 
+    def _tracking_distances(self):
+        """_compute_tracking_distance for all (blob, tracked blob) pairs at once: the same int16 /
+        int32 / float64 arithmetic element for element; a tracked blob's gate is evaluated once."""
+        gates = [self._compute_tracking_space(t['bottom']) for t in self.tracked_blobs_]
+        r_maj = np.array([g[0] for g in gates], dtype=np.int32)
+        r_min = np.array([g[1] for g in gates], dtype=np.int32)
+        delta = (np.array([b['center'] for b in self.blobs_])[:, None, :]
+                 - np.array([t['center'] for t in self.tracked_blobs_])[None, :, :])
+        ok = (r_maj > 0) & (r_min > 0)
+        with np.errstate(divide='ignore', invalid='ignore', over='ignore'):
+            return np.where(ok[None, :], delta[..., 0]**2 / r_maj**2 + delta[..., 1]**2 / r_min**2, 0.0)
+
     def _create_tracked_blob(self, i_blob):
         blob = self.blobs_[i_blob]
         return {
             'contour': blob['contour'].copy(), 'anchor': blob['anchor'], 'bottom': blob['bottom'],
             'center': blob['center'], 'center_first': blob['center'], 'presence': 1, 'absence': 0,
-            'filtered': set(['presence', 'distance']), 'already_in_alarm': False,
+            'filtered': set(['presence', 'distance']), 'already_in_alarm': False, 'bbox': blob.get('bbox'),
         }
 
     def _compute_tracking_distance(self, i_tracked_blob, i_blob):
@@ -384,6 +415,7 @@ class GOFPID():
         tracked['contour'] = blob['contour'].copy()
         for key in ('anchor', 'bottom', 'center'):
             tracked[key] = blob[key]
+        tracked['bbox'] = blob.get('bbox')
         tracked['absence'] = 0
         tracked['presence'] += 1
         if tracked['presence'] >= self.post_filter['presence_min']:
@@ -414,7 +446,7 @@ class GOFPID():
                                              False) >= 0
             (tracked['filtered'].discard if inside else tracked['filtered'].add)('perimeter')
 
-            _, _, width, height = hostcv.boundingRect(tracked['contour'])
+            _, _, width, height = tracked.get('bbox') or hostcv.boundingRect(tracked['contour'])
             area_persp = self._predict_perspective('area', tracked['bottom'][1])
             big_enough = width * height > area_persp * self.post_filter['perspective_coeff']
             (tracked['filtered'].discard if big_enough else tracked['filtered'].add)('perspective')

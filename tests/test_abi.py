@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
 def test_abi_version_and_strerror_without_gpu():
     from pygofpid_amd import _lib
     lib = _lib.load()
-    assert lib.gof_abi_version() == 2
+    assert lib.gof_abi_version() == 3
     assert lib.gof_strerror(_lib.EINVAL) == b"invalid argument"
     p = _lib.Mog2Params()
     lib.gof_mog2_default_params(C.byref(p))

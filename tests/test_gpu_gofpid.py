@@ -233,3 +233,28 @@ def test_gofpid_detect_many_equals_detect(G):
     assert np.array_equal(a.foreground_mask_, b.foreground_mask_)
     with pytest.raises(ValueError):
         b.detect_many([clip.frame(0)[:-1]])
+
+
+def test_gofpid_detect_many_long_list_is_chunked_and_pipelined(G):
+    """A list far longer than one device batch (8 frames): detect_many works through it in
+    pipelined batches -- bounded memory, the upload of batch k + 1 beside the kernels of batch k
+    and the host steps of batch k -- with the results of frame-by-frame detect(); a frame of
+    another shape anywhere in the list is refused BEFORE any frame is consumed."""
+    h, w = 120, 200
+    clip = Clip(h, w, 3, seed=31, n_objects=3)
+    frames = [clip.frame(t) for t in range(61)]
+    a = G(post_filter=post_filter.copy()).initialize()
+    b = G(post_filter=post_filter.copy()).initialize()
+    want = [a.detect(f) for f in frames]
+    bad = frames[:20] + [frames[20][:, :-4]] + frames[21:]
+    with pytest.raises(ValueError):
+        b.detect_many(bad)
+    assert not b.input_shape_ and b._fused is None          # nothing was consumed
+    assert b.detect_many(frames[:37]) == want[:37]          # first call: 1 + 36 frames = 5 batches
+    assert b._fused._slot_blobs[0].n_images <= 8 and b._fused._slot_blobs[1].n_images <= 8
+    assert b.detect_many(frames[37:]) == want[37:]
+    assert np.array_equal(a.foreground_mask_, b.foreground_mask_)
+    for x, y in zip(a.tracked_blobs_, b.tracked_blobs_):
+        assert x['presence'] == y['presence'] and x['filtered'] == y['filtered']
+        assert np.array_equal(x['contour'], y['contour'])
+    assert b.detect(frames[5]) == a.detect(frames[5])       # and back to single frames

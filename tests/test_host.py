@@ -221,3 +221,45 @@ def test_blob_records_reproduce_reference_pins(dtype):
     bottom, center = blobs.bottom_and_center(recs[0], dtype=dtype)
     assert bottom.dtype == dtype and bottom.tolist() == [5, 10] and center.tolist() == [5, 5]
     assert blobs.moments_of(recs[0]) == hostcv.moments(pts.reshape(-1, 1, 2))
+
+
+def test_tracking_distances_all_pairs_equal_the_scalar_rule():
+    """GOFPID._track_blob evaluates all (blob, tracked blob) gate distances at once; element for
+    element that is _compute_tracking_distance (reference pipeline.py:630-647): int16 centre
+    differences (wrapping squares included), int32 radii, float64 quotients, 0 for an empty gate."""
+    import warnings
+    from pygofpid_amd.pipeline import GOFPID
+    rng = np.random.default_rng(3)
+    g = GOFPID().initialize()
+    g.input_shape_ = (480, 640, 3)
+    g._calib_first_frame()
+    mk = lambda: {'center': rng.integers(-300, 900, 2).astype(np.int16),
+                  'bottom': rng.integers(-50, 600, 2).astype(np.int16),
+                  'contour': np.zeros((4, 1, 2), np.int32), 'anchor': np.zeros(2, np.int16)}
+    g.blobs_ = [mk() for _ in range(9)]
+    tracked = [dict(mk(), center_first=np.zeros(2, np.int16), presence=1, absence=0,
+                    filtered=set(), already_in_alarm=False) for _ in range(7)]
+    g.tracked_blobs_ = [dict(t) for t in tracked]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        want = np.array([[g._compute_tracking_distance(j, i) for j in range(7)] for i in range(9)], dtype=np.float64)
+        got = g._tracking_distances()
+    assert got.shape == (9, 7) and got.dtype == np.float64
+    assert np.array_equal(got, want)
+
+
+def test_bottoms_and_centers_vectorised_equals_per_record():
+    from pygofpid_amd import blobs as gb
+    rng = np.random.default_rng(11)
+    mask = np.zeros((200, 300), np.uint8)
+    for _ in range(12):
+        x, y = int(rng.integers(0, 260)), int(rng.integers(0, 170))
+        mask[y:y + int(rng.integers(8, 30)), x:x + int(rng.integers(8, 40))] = 255
+    recs, pts = gb.host_result(mask, 20.0)
+    assert len(recs) > 3
+    bottoms, centers = gb.bottoms_and_centers(recs)
+    for i, r in enumerate(recs):
+        b, c = gb.bottom_and_center(r)
+        assert np.array_equal(bottoms[i], b) and np.array_equal(centers[i], c) and bottoms.dtype == b.dtype
+        x0, y0, w, h = hostcv.boundingRect(gb.contours_of(recs, pts)[i])
+        assert (x0, y0, w, h) == (r['xmin'], r['ymin'], r['xmax'] - r['xmin'] + 1, r['ymax'] - r['ymin'] + 1)
