@@ -58,7 +58,7 @@ class BlobExtractor:
 
     def result(self, image):
         """(records, points) of one image of the last extraction -- records: structured
-        array (RECORD_DTYPE) in cv2's contour order, points: (n_points, 2) int32 (x, y) --
+        array (RECORD_DTYPE) in hostcv.CONTOUR_ORDER (cv2's order of the contour list), points: (n_points, 2) int32 (x, y) --
         or None when the device flagged an overflow (fall back to the mask)."""
         nb, npts, fl = C.c_int(), C.c_int(), C.c_int()
         lib = _lib.load()
@@ -78,6 +78,12 @@ class BlobExtractor:
         pts = np.zeros((npts.value, 2), np.int32)
         _lib.check(lib.gof_blobs_fetch(self._h, int(image), recs.ctypes.data_as(C.c_void_p), nb.value,
                                        pts.ctypes.data_as(C.c_void_p), npts.value))
+        from . import hostcv
+        if hostcv.CONTOUR_ORDER == "cv2" and nb.value > 1:
+            # the device reports raster order: records and their point runs into cv2's list order
+            recs = np.ascontiguousarray(recs[::-1])
+            pts = np.concatenate([pts[o:o + n] for o, n in zip(recs["point_offset"], recs["n_points"])])
+            recs["point_offset"] = np.cumsum(recs["n_points"]) - recs["n_points"]
         return recs, pts
 
     def close(self):

@@ -13,9 +13,24 @@ import numpy as np
 from . import _lib
 
 
+# Order of a returned contour list.  cv2's findContours meets the borders in raster order of their
+# first pixel but hands the list back REVERSED -- the border found last comes first [OPENCV-RECALL;
+# unpinned: neither the reference's tests nor its files hold a contour list].  GOFPID._track_blob
+# is greedy over blobs_ in that order (reference pipeline.py:614-622), so the order can decide
+# which track a blob takes over.  "cv2": reversed discovery order (the default since round 3);
+# "raster": order of discovery (what rounds 1-2 returned).  The C ABI (gof_find_external_contours,
+# gof_blobs) always reports raster order; this switch is applied where its results become lists.
+CONTOUR_ORDER = "cv2"
+
+
+def in_contour_order(items):
+    """`items` (a sequence in raster order of the borders' first pixels) in CONTOUR_ORDER."""
+    return items[::-1] if CONTOUR_ORDER == "cv2" else items
+
+
 def findContours(mask):
     """cv.findContours(mask, RETR_EXTERNAL, CHAIN_APPROX_NONE)[contours]:
-    a list of (n, 1, 2) int32 arrays of (x, y) border points
+    a list of (n, 1, 2) int32 arrays of (x, y) border points, in CONTOUR_ORDER
     (reference call: helpers.py:139-143)."""
     m = _lib.as_u8(mask, "mask")
     if m.ndim == 3 and m.shape[2] == 1:
@@ -36,7 +51,7 @@ def findContours(mask):
     finally:
         lib.gof_free(pts)
         lib.gof_free(offs)
-    return [p[o[k]:o[k + 1]] for k in range(n.value)]
+    return in_contour_order([p[o[k]:o[k + 1]] for k in range(n.value)])
 
 
 def _xy(contour):

@@ -87,7 +87,7 @@ def extract(m, min_a2=200):
 
 def check(m, min_a2=200):
     ref = [c for c in hostcv.findContours(m) if hostcv.contourArea(c) * 2 >= min_a2]
-    got = extract(m, min_a2)
+    got = hostcv.in_contour_order(extract(m, min_a2))   # (the model lists borders in raster order)
     assert len(ref) == len(got), (len(ref), len(got))
     for c, g in zip(ref, got):
         assert c.shape == g['pts'].shape and np.array_equal(c, g['pts']), (c.reshape(-1, 2)[:8], g['pts'].reshape(-1, 2)[:8])

@@ -264,3 +264,31 @@ def test_reference_pins_through_the_device_path():
     for dtype in (np.int16, np.uint16, np.int32, np.uint32):
         bottom, center = blobs.bottom_and_center(recs[0], dtype=dtype)
         assert bottom.tolist() == [5, 10] and center.tolist() == [5, 5]
+
+
+def test_device_extraction_against_the_independent_crack_model():
+    """The HIP path meets a checker that shares no code with the product library: the plain-loop
+    crack-cycle model of tests/crack_model.py (pure Python: cracks, successor permutation, cycle
+    sums, nesting depth) -- contours, order, points, shoelace sums and boxes, on random and
+    structured small masks, for several area thresholds."""
+    import crack_model
+    from pygofpid_amd import blobs, hostcv
+    rng = np.random.default_rng(2024)
+    n_checked = 0
+    for it in range(60):
+        h, w = int(rng.integers(1, 40)), int(rng.integers(1, 70))
+        m = _random_mask(rng, h, w, it % 4)
+        ex = blobs.BlobExtractor(1, h, w, crack_capacity=2 * h * w + 16)
+        for min_a2 in (0, 3, 40):
+            got = ex.extract(m, min_a2 / 2.0)[0]
+            assert got is not None
+            recs, pts = got
+            want = hostcv.in_contour_order(crack_model.extract(m, min_a2))
+            assert len(recs) == len(want), (it, min_a2, len(recs), len(want))
+            for r, g in zip(recs, want):
+                c = pts[r["point_offset"]:r["point_offset"] + r["n_points"]].reshape(-1, 1, 2)
+                assert c.shape == g["pts"].shape and np.array_equal(c, g["pts"])
+                assert (int(r["a00"]), int(r["a10"]), int(r["a01"])) == (g["a00"], g["a10"], g["a01"])
+                assert (r["xmin"], r["ymin"], r["xmax"], r["ymax"]) == g["bbox"]
+                n_checked += 1
+    assert n_checked > 150

@@ -220,3 +220,47 @@ def test_pipeline_fused_convert(oracle, code, cin):
     assert np.array_equal(pipe.last_masks()[0, 0], ref.apply(gray(frame(13)))) and res[0] is not None
     with pytest.raises(ValueError):
         ForegroundPipeline((h, w, 1), convert=code)
+
+
+def test_warm_start_rccl_one_rank_rehearsal():
+    """The RCCL calls of the multi-GPU path executed on hardware: a ONE-rank "nccl" process group
+    (GOF_DIST_FORCE=1) in a child process -- init with the device id, barrier, the MAX / SUM
+    reductions of bench.py's timing on device tensors, and distributed.warm_start() with its
+    all_gather geometry check and the two broadcasts -- after which the model must be unchanged
+    (a twin pipeline keeps giving identical masks).  N > 1 on real xGMI is the driver's to run."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import os, sys
+import numpy as np
+import torch
+sys.path.insert(0, os.getcwd())
+from pygofpid_amd import distributed as gd
+from pygofpid_amd.foreground import ForegroundPipeline
+from pygofpid_amd.synth import Clip
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+assert gd.init(backend="nccl", device=dev) == (0, 1)
+assert torch.distributed.is_initialized() and torch.distributed.get_backend() == "nccl"
+gd.barrier()
+assert gd.max_over_ranks(2.5, device=dev) == 2.5 and gd.sum_over_ranks(4.0, device=dev) == 4.0
+h, w, c = 64, 96, 3
+clip = Clip(h, w, c, seed=9)
+a, b = ForegroundPipeline((h, w, c), streams=2), ForegroundPipeline((h, w, c), streams=2)
+for t in range(6):
+    f = np.stack([clip.frame(t), clip.frame(t + 50)])
+    assert np.array_equal(a.apply(f), b.apply(f))
+assert gd.warm_start(a) == 6
+for t in range(6, 14):
+    f = np.stack([clip.frame(t), clip.frame(t + 50)])
+    assert np.array_equal(a.apply(f), b.apply(f))
+gd.barrier()
+torch.distributed.destroy_process_group()
+print("RCCL-REHEARSAL-OK")
+'''
+    from conftest import ROOT
+    env = dict(os.environ, GOF_DIST_FORCE="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0",
+               MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "RCCL-REHEARSAL-OK" in out.stdout, (out.stdout[-800:], out.stderr[-1500:])

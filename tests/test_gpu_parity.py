@@ -576,6 +576,32 @@ def test_pipeline_full_hd_multi_frame(oracle):
         _assert_state_equal(got, refs[s].export())
 
 
+def test_pipeline_sharding_unit_8x1080p(oracle):
+    """The per-GPU share of BASELINE config 4 and the unit bench.py times: EIGHT 1080p streams
+    through 8-frame launches (two of them: the learning-rate ramp, new modes, trails), every mask
+    of every stream and the final float32 model state of every stream against the oracle."""
+    from pygofpid_amd.foreground import ForegroundPipeline
+    h, w, c, S, T = 1080, 1920, 3, 8, 8
+    clips = [Clip(h, w, c, seed=70 + s, n_objects=3 + s % 3) for s in range(S)]
+    gpu = ForegroundPipeline((h, w, c), streams=S)
+    refs = [oracle.Pipeline(h, w, c) for _ in range(S)]
+    for r in range(2):
+        frames = np.stack([np.stack([cl.frame(T * r + i) for cl in clips]) for i in range(T)])
+        got = gpu.apply_many(frames)
+        assert got.shape == (T, S, h, w)
+        for i in range(T):
+            for s in range(S):
+                want = refs[s].apply(frames[i, s])
+                assert np.array_equal(got[i, s], want), (T * r + i, s, int((got[i, s] != want).sum()))
+        del frames, got
+    st = gpu.mog2_state()
+    n = h * w
+    for s in range(S):
+        got = {"modes": st["modes"][s * n:(s + 1) * n], "weight": st["weight"][:, s * n:(s + 1) * n],
+               "var": st["var"][:, s * n:(s + 1) * n], "mean": st["mean"][:, :, s * n:(s + 1) * n]}
+        _assert_state_equal(got, refs[s].export())
+
+
 def test_pipeline_4k_open_close_multi_frame(oracle):
     """BASELINE config 3 geometry through an 8-frame launch and the 7x7 open / close chain."""
     from pygofpid_amd.foreground import ForegroundPipeline
