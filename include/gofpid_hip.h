@@ -61,7 +61,7 @@ enum {
 };
 
 enum { GOF_ERODE = 0, GOF_DILATE = 1 };
-enum { GOF_DET_MOG2 = 0, GOF_DET_FD = 1 };
+enum { GOF_DET_MOG2 = 0, GOF_DET_FD = 1, GOF_DET_KNN = 2 };
 enum { GOF_BLUR_NONE = 0, GOF_BLUR_GAUSS = 1, GOF_BLUR_BOX = 2 };
 
 #define GOF_MAX_MODES 5      /* cv2 MOG2 default nmixtures                 */
@@ -70,6 +70,7 @@ enum { GOF_BLUR_NONE = 0, GOF_BLUR_GAUSS = 1, GOF_BLUR_BOX = 2 };
 
 typedef struct gof_ctx gof_ctx;
 typedef struct gof_mog2 gof_mog2;
+typedef struct gof_knn gof_knn;
 typedef struct gof_fd gof_fd;
 typedef struct gof_pipeline gof_pipeline;
 
@@ -89,6 +90,17 @@ typedef struct gof_mog2_params {
     int shadow_value;         /* 127  */
 } gof_mog2_params;
 
+/* cv.createBackgroundSubtractorKNN() defaults [OPENCV-RECALL bgfg_KNN.cpp]. */
+typedef struct gof_knn_params {
+    int history;              /* 500  */
+    int nsamples;             /* 7    samples per set (short / mid / long term) */
+    float dist2_threshold;    /* 400  */
+    int knn;                  /* 2    flagged neighbours that make a pixel background */
+    float tau;                /* 0.5  shadow threshold */
+    int detect_shadows;       /* 1    */
+    int shadow_value;         /* 127  */
+} gof_knn_params;
+
 /* One mat_morph entry (pipeline.py:177-186, 473-475). */
 typedef struct gof_morph_op {
     int op;                   /* GOF_ERODE | GOF_DILATE                    */
@@ -103,7 +115,7 @@ typedef struct gof_pipeline_desc {
     int blur;                 /* GOF_BLUR_NONE | GOF_BLUR_GAUSS | GOF_BLUR_BOX */
     int blur_kw, blur_kh;     /* odd                                        */
     double blur_sigma_x, blur_sigma_y;
-    int detector;             /* GOF_DET_MOG2 | GOF_DET_FD                 */
+    int detector;             /* GOF_DET_MOG2 | GOF_DET_FD | GOF_DET_KNN (cv2 defaults) */
     gof_mog2_params mog2;
     double fd_threshold;
     int n_morph;
@@ -176,6 +188,26 @@ int gof_mog2_set_nframes(gof_mog2 *m, int nframes);
  * device buffer of gof_mog2_device_state()'s size; synchronous */
 int gof_mog2_state_copy(gof_mog2 *m, void *d_buf, int to_model);
 
+/* ---- step 2c: KNN  (replaces cv.createBackgroundSubtractorKNN() and its .apply(X),
+ *      pipeline.py:233-234 and :470; exercised by tests/test_pipeline.py:98-109) ------------
+ * cv2's model (three sets of nsamples samples per pixel, sample = channel bytes + flag byte),
+ * rule (kNN flagged neighbours within dist2Threshold -> background, shadow test with tau, else
+ * foreground) and staggered refresh.  cv2 draws every pixel's next refresh slot with rand() in a
+ * row-parallel loop, so its own masks are not reproducible run to run; here the draw is a hash of
+ * (pixel, frame, set) -- identical results on every run and bit-identical to the CPU restatement
+ * this repository tests against; parity with cv2 itself is unpinnable by construction.
+ * frames: streams x (h, w, c) uint8; masks: streams x (h, w) in {0, shadow_value, 255}. */
+void gof_knn_default_params(gof_knn_params *p);
+int gof_knn_create(gof_ctx *ctx, int streams, int h, int w, int c, const gof_knn_params *p, gof_knn **out);
+void gof_knn_destroy(gof_knn *k);
+int gof_knn_apply_host(gof_knn *k, const uint8_t *frames, uint8_t *masks);
+int gof_knn_apply_dev(gof_knn *k, const void *d_frames, void *d_masks, void *stream);
+int gof_knn_nframes(const gof_knn *k);
+/* the model as byte planes (host buffers), n = streams*h*w: samples[3 nsamples][c + 1][n] (sets in
+ * the order short, mid, long; last byte of a sample = its flag), state[6][n] = slot of the next
+ * short / mid / long refresh, write index of the short / mid / long set */
+int gof_knn_export(gof_knn *k, uint8_t *samples, uint8_t *state);
+
 /* ---- step 2b: frame differencing (replaces FrameDifferencing.apply,
  *      segmentation.py:40-70) ---------------------------------------------- */
 int gof_fd_create(gof_ctx *ctx, int streams, int h, int w, int c, double threshold, gof_fd **out);
@@ -209,7 +241,8 @@ int gof_pipeline_apply_dev_many(gof_pipeline *p, const void *d_frames, void *d_m
  * The pipeline must have been created with c == 1; every apply then takes
  * streams x (h, w, c_in) frames.  c_in == 0 switches the conversion off again. */
 int gof_pipeline_set_convert(gof_pipeline *p, int c_in, int rgb_order);
-gof_mog2 *gof_pipeline_mog2(gof_pipeline *p);   /* NULL for an FD pipeline */
+gof_mog2 *gof_pipeline_mog2(gof_pipeline *p);
+gof_knn *gof_pipeline_knn(gof_pipeline *p);    /* the pipeline's KNN model, or NULL */
 /* mean number of Gaussian modes in use per pixel (m-bar of the byte model) */
 int gof_pipeline_mean_modes(gof_pipeline *p, double *mean_modes);
 /* Algorithmic HBM bytes of one apply of n_frames frames, given m-bar:

@@ -79,6 +79,12 @@ class Mog2Params(C.Structure):
     ]
 
 
+class KnnParams(C.Structure):
+    _fields_ = [("history", C.c_int), ("nsamples", C.c_int), ("dist2_threshold", C.c_float),
+                ("knn", C.c_int), ("tau", C.c_float), ("detect_shadows", C.c_int),
+                ("shadow_value", C.c_int)]
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -123,6 +129,18 @@ def lib():
         L.gofo_pipeline_mean_modes.restype = C.c_double
         L.gofo_pipeline_mog2.argtypes = [C.c_void_p]
         L.gofo_pipeline_mog2.restype = C.c_void_p
+        L.gofo_pipeline_knn.argtypes = [C.c_void_p]
+        L.gofo_pipeline_knn.restype = C.c_void_p
+        L.gofo_knn_default_params.argtypes = [C.POINTER(KnnParams)]
+        L.gofo_knn_create.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(KnnParams)]
+        L.gofo_knn_create.restype = C.c_void_p
+        L.gofo_knn_destroy.argtypes = [C.c_void_p]
+        L.gofo_knn_nframes.argtypes = [C.c_void_p]
+        L.gofo_knn_nframes.restype = C.c_int
+        L.gofo_knn_apply.argtypes = [C.c_void_p, _u8p, _u8p]
+        L.gofo_knn_export.argtypes = [C.c_void_p, _u8p, _u8p]
+        L.gofo_knn_draw.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
+        L.gofo_knn_draw.restype = C.c_uint32
         _lib = L
     return _lib
 
@@ -258,6 +276,50 @@ class MOG2:
             self._h = None
 
 
+class KNN:
+    """cv.createBackgroundSubtractorKNN() restated (defaults unless overridden); its update draws
+    come from gofo_knn_draw (see gof_oracle.c: parity with cv2 itself is unpinnable by construction)."""
+
+    def __init__(self, **overrides):
+        self._params = KnnParams()
+        lib().gofo_knn_default_params(C.byref(self._params))
+        for k, v in overrides.items():
+            setattr(self._params, k, v)
+        self._h = None
+        self._shape = None
+
+    def apply(self, x):
+        x, h, w, c = _as_hwc(x)
+        if self._h is None:
+            self._h = lib().gofo_knn_create(h, w, c, C.byref(self._params))
+            if not self._h:
+                raise ValueError("bad KNN parameters")
+            self._shape = (h, w, c)
+        assert (h, w, c) == self._shape
+        out = np.empty((h, w), dtype=np.uint8)
+        lib().gofo_knn_apply(self._h, _p8(x), _p8(out))
+        return out
+
+    def export(self):
+        """-> {"samples": (3 nN, c + 1, N) uint8 (last byte of a sample = its flag),
+        "state": (6, N) uint8 = next short / mid / long, index short / mid / long}"""
+        return _knn_export(self._h, self._shape, self._params.nsamples)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().gofo_knn_destroy(self._h)
+            self._h = None
+
+
+def _knn_export(handle, shape, nsamples):
+    h, w, c = shape
+    n = h * w
+    samples = np.empty((3 * nsamples, c + 1, n), np.uint8)
+    state = np.empty((6, n), np.uint8)
+    lib().gofo_knn_export(handle, _p8(samples), _p8(state))
+    return {"samples": samples, "state": state}
+
+
 class Pipeline:
     """Steps 1-3 of GOFPID.detect [REF pipeline.py:461-476], threaded over rows.
 
@@ -272,7 +334,7 @@ class Pipeline:
         ks = (C.c_int * max(1, len(morph)))(*[int(m[1]) for m in morph])
         self.shape = (h, w, c)
         self._h = lib().gofo_pipeline_create(h, w, c, blur_k, float(blur_sigma),
-                                             0 if detector == "MOG2" else 1, float(fd_thr),
+                                             {"MOG2": 0, "FD": 1, "KNN": 2}[detector], float(fd_thr),
                                              len(morph), ops, ks, threads)
         if not self._h:
             raise ValueError("bad pipeline configuration")
@@ -292,7 +354,10 @@ class Pipeline:
         return lib().gofo_pipeline_mean_modes(self._h)
 
     def export(self):
-        """SoA planes of the MOG2 model (as MOG2.export), or None for FD."""
+        """SoA planes of the MOG2 model (as MOG2.export), the KNN model (as KNN.export), or None for FD."""
+        k = lib().gofo_pipeline_knn(self._h)
+        if k:
+            return _knn_export(k, self.shape, 7)
         m = lib().gofo_pipeline_mog2(self._h)
         if not m:
             return None

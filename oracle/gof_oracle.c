@@ -55,6 +55,9 @@
  *                         REFLECT_101.                       -> gofo_gaussian_blur
  *   pipeline.py:232,470   cv.createBackgroundSubtractorMOG2().apply(X)
  *                                                            -> gofo_mog2_apply
+ *   pipeline.py:233-234   cv.createBackgroundSubtractorKNN().apply(X)
+ *                         (cv2's own output is not reproducible: rand() in a
+ *                         row-parallel loop; see the section)  -> gofo_knn_apply
  *   segmentation.py:40-70 FrameDifferencing.apply            -> gofo_fd_apply
  *   pipeline.py:473-475   d['fun'](mask, d['kernel']) with cv.erode / cv.dilate
  *                                                            -> gofo_morph
@@ -663,6 +666,259 @@ void gofo_morph(int op, const uint8_t *src, uint8_t *dst, int h, int w,
 }
 
 /* ------------------------------------------------------------------------- */
+/* BackgroundSubtractorKNN  [REF pipeline.py:233-234: cv.createBackgroundSubtractorKNN()] */
+/* ------------------------------------------------------------------------- */
+/* cv2's K-nearest-neighbours subtractor (Zivkovic & van der Heijden 2006) with all defaults
+ * [OPENCV-RECALL bgfg_KNN.cpp]: per pixel three sets (short / mid / long term) of nN = 7 samples,
+ * a sample = the pixel's channel bytes + one flag byte ("was background when stored"); a pixel is
+ * background when at least kNN = 2 FLAGGED samples lie within dist2Threshold = 400 of it, shadow
+ * (127) when that many flagged samples pass the chromaticity test (tau 0.5), else foreground.
+ * The sets are refreshed at staggered times: a set's counter runs 0 .. nUpdate - 1 (nUpdate from
+ * the learning rate 1 / min(2 n, history), history 500), a pixel is refreshed in the frame where
+ * the counter meets its own slot, and at the end of a cycle every pixel DRAWS the slot of the next.
+ *
+ * PARITY WITH cv2: UNPINNABLE BY CONSTRUCTION.  cv2 draws those slots with C rand() inside a loop
+ * it runs row-parallel, so its own output depends on thread scheduling: two cv2 runs differ, and
+ * no restatement can match "it" bit for bit.  This restatement keeps cv2's model, thresholds,
+ * update structure and statement order and replaces the draw by a counter-based generator keyed
+ * on (pixel, frame, set) -- gofo_knn_draw below -- so that the C oracle and the HIP kernel are
+ * bit-identical to EACH OTHER (masks and every model byte); against cv2 only the statistics match.
+ */
+typedef struct gofo_knn_params {
+    int history;            /* 500 */
+    int nsamples;           /* nN: samples per set, 7 */
+    float dist2_threshold;  /* 400 */
+    int knn;                /* 2 = max(1, cvRound(0.1 * nN * 3 + 0.40)) */
+    float tau;              /* 0.5 */
+    int detect_shadows;     /* 1 */
+    int shadow_value;       /* 127 */
+} gofo_knn_params;
+
+void gofo_knn_default_params(gofo_knn_params *p)
+{
+    p->history = 500;
+    p->nsamples = 7;
+    p->dist2_threshold = 20.0f * 20.0f;
+    p->knn = 2;
+    p->tau = 0.5f;
+    p->detect_shadows = 1;
+    p->shadow_value = 127;
+}
+
+#define GOFO_KNN_MAX_SAMPLES 16
+
+typedef struct gofo_knn {
+    gofo_knn_params p;
+    int h, w, c;
+    int nframes;
+    int short_counter, mid_counter, long_counter;
+    uint8_t *model;       /* [h*w][3*nN][c+1]: short set, mid set, long set */
+    uint8_t *next;        /* [h*w][3]: slot of the next short / mid / long refresh */
+    uint8_t *index;       /* [h*w][3]: write position in the short / mid / long set */
+} gofo_knn;
+
+gofo_knn *gofo_knn_create(int h, int w, int c, const gofo_knn_params *p)
+{
+    if (h <= 0 || w <= 0 || c <= 0 || c > GOFO_MAX_CH)
+        return NULL;
+    gofo_knn *m = (gofo_knn *)calloc(1, sizeof(*m));
+    if (p)
+        m->p = *p;
+    else
+        gofo_knn_default_params(&m->p);
+    if (m->p.nsamples < 1 || m->p.nsamples > GOFO_KNN_MAX_SAMPLES || m->p.knn < 1 || m->p.history < 1) {
+        free(m);
+        return NULL;
+    }
+    m->h = h;
+    m->w = w;
+    m->c = c;
+    size_t n = (size_t)h * w;
+    m->model = (uint8_t *)calloc(n * 3 * m->p.nsamples * (c + 1), 1);   /* cv2: all zero, flags clear */
+    m->next = (uint8_t *)calloc(n * 3, 1);
+    m->index = (uint8_t *)calloc(n * 3, 1);
+    return m;
+}
+
+void gofo_knn_destroy(gofo_knn *m)
+{
+    if (!m)
+        return;
+    free(m->model);
+    free(m->next);
+    free(m->index);
+    free(m);
+}
+
+int gofo_knn_nframes(const gofo_knn *m) { return m->nframes; }
+
+/* The draw that replaces rand(): 31 bits (glibc's range) from (pixel, frame, set) -- the
+ * "lowbias32" integer hash.  pixel = y * w + x, frame = the 1-based frame count, set 0 / 1 / 2. */
+uint32_t gofo_knn_draw(uint32_t pixel, uint32_t frame, uint32_t set)
+{
+    uint32_t x = pixel * 0x9E3779B1u ^ (frame * 0x85EBCA77u + set * 0xC2B2AE3Du);
+    x ^= x >> 16;
+    x *= 0x7FEB352Du;
+    x ^= x >> 15;
+    x *= 0x846CA68Bu;
+    x ^= x >> 16;
+    return x >> 1;
+}
+
+/* nShortUpdate, nMidUpdate, nLongUpdate of this frame [OPENCV-RECALL apply()] */
+static void knn_rates(const gofo_knn *m, int nframes, int *ns, int *nm, int *nl)
+{
+    double lr = 1.0 / (double)(2 * nframes < m->p.history ? 2 * nframes : m->p.history);
+    int nN = m->p.nsamples;
+    int Kshort = (int)(log(0.7) / log(1 - lr)) + 1;
+    int Kmid = (int)(log(0.4) / log(1 - lr)) - Kshort + 1;
+    int Klong = (int)(log(0.1) / log(1 - lr)) - Kshort - Kmid + 1;
+    *ns = Kshort / nN + 1;
+    *nm = Kmid / nN + 1;
+    *nl = Klong / nN + 1;
+}
+
+/* _cvCheckPixelBackgroundNP: 1 background, 2 shadow, 0 foreground; *include: store the pixel as
+ * a background sample */
+static int knn_check(const gofo_knn_params *P, const uint8_t *data, int nch, const uint8_t *model,
+                     uint8_t *include)
+{
+    int Pbf = 0, Pb = 0, nN = P->nsamples, ndata = nch + 1;
+    float dData[GOFO_MAX_CH];
+    *include = 0;
+    for (int n = 0; n < nN * 3; n++) {
+        const uint8_t *mean_m = model + n * ndata;
+        float dist2;
+        if (nch == 3) {
+            dData[0] = (float)mean_m[0] - data[0];
+            dData[1] = (float)mean_m[1] - data[1];
+            dData[2] = (float)mean_m[2] - data[2];
+            dist2 = dData[0] * dData[0] + dData[1] * dData[1] + dData[2] * dData[2];
+        } else {
+            dist2 = 0.f;
+            for (int c = 0; c < nch; c++) {
+                dData[c] = (float)mean_m[c] - data[c];
+                dist2 += dData[c] * dData[c];
+            }
+        }
+        if (dist2 < P->dist2_threshold) {
+            Pbf++;
+            if (mean_m[nch]) {
+                Pb++;
+                if (Pb >= P->knn) {
+                    *include = 1;
+                    return 1;
+                }
+            }
+        }
+    }
+    if (Pbf >= P->knn)
+        *include = 1;
+    int Ps = 0;
+    if (P->detect_shadows) {
+        for (int n = 0; n < nN * 3; n++) {
+            const uint8_t *mean_m = model + n * ndata;
+            if (mean_m[nch]) {
+                float numerator = 0.0f, denominator = 0.0f;
+                for (int c = 0; c < nch; c++) {
+                    numerator += (float)data[c] * mean_m[c];
+                    denominator += (float)mean_m[c] * mean_m[c];
+                }
+                if (denominator == 0)
+                    return 0;
+                if (numerator <= denominator && numerator >= P->tau * denominator) {
+                    float a = numerator / denominator;
+                    float dist2a = 0.0f;
+                    for (int c = 0; c < nch; c++) {
+                        float dD = a * mean_m[c] - data[c];
+                        dist2a += dD * dD;
+                    }
+                    if (dist2a < P->dist2_threshold * a * a) {
+                        Ps++;
+                        if (Ps >= P->knn)
+                            return 2;
+                    }
+                }
+            }
+        }
+    }
+    return 0;
+}
+
+/* frame (h,w,c) uint8 -> mask (h,w) in {0, shadow_value, 255} */
+void gofo_knn_apply(gofo_knn *m, const uint8_t *frame, uint8_t *mask)
+{
+    int h = m->h, w = m->w, nch = m->c, nN = m->p.nsamples, ndata = nch + 1;
+    m->nframes++;
+    int nShort, nMid, nLong;
+    knn_rates(m, m->nframes, &nShort, &nMid, &nLong);
+    int LongCounter = m->long_counter, MidCounter = m->mid_counter, ShortCounter = m->short_counter;
+    m->short_counter++;
+    m->mid_counter++;
+    m->long_counter++;
+    if (m->short_counter >= nShort)
+        m->short_counter = 0;
+    if (m->mid_counter >= nMid)
+        m->mid_counter = 0;
+    if (m->long_counter >= nLong)
+        m->long_counter = 0;
+    const uint32_t frame_no = (uint32_t)m->nframes;
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < h; y++) {
+        for (int x = 0; x < w; x++) {
+            size_t i = (size_t)y * w + x;
+            const uint8_t *data = frame + i * nch;
+            uint8_t *model = m->model + i * 3 * nN * ndata;
+            uint8_t *next = m->next + i * 3, *index = m->index + i * 3;
+            uint8_t include = 0;
+            int result = knn_check(&m->p, data, nch, model, &include);
+            /* _cvUpdatePixelBackgroundNP: offsets first, then long <- mid, mid <- short, short <- pixel */
+            size_t offsetLong = (size_t)ndata * (index[2] + nN * 2);
+            size_t offsetMid = (size_t)ndata * (index[1] + nN * 1);
+            size_t offsetShort = (size_t)ndata * (index[0]);
+            if (next[2] == LongCounter) {
+                memcpy(model + offsetLong, model + offsetMid, ndata);
+                index[2] = (index[2] >= nN - 1) ? 0 : (uint8_t)(index[2] + 1);
+            }
+            if (LongCounter == nLong - 1)
+                next[2] = (uint8_t)(gofo_knn_draw((uint32_t)i, frame_no, 2) % (uint32_t)nLong);
+            if (next[1] == MidCounter) {
+                memcpy(model + offsetMid, model + offsetShort, ndata);
+                index[1] = (index[1] >= nN - 1) ? 0 : (uint8_t)(index[1] + 1);
+            }
+            if (MidCounter == nMid - 1)
+                next[1] = (uint8_t)(gofo_knn_draw((uint32_t)i, frame_no, 1) % (uint32_t)nMid);
+            if (next[0] == ShortCounter) {
+                memcpy(model + offsetShort, data, nch);
+                model[offsetShort + nch] = include;
+                index[0] = (index[0] >= nN - 1) ? 0 : (uint8_t)(index[0] + 1);
+            }
+            if (ShortCounter == nShort - 1)
+                next[0] = (uint8_t)(gofo_knn_draw((uint32_t)i, frame_no, 0) % (uint32_t)nShort);
+            mask[i] = result == 0 ? 255 : (result == 1 ? 0 : (uint8_t)m->p.shadow_value);
+        }
+    }
+}
+
+/* The model as planes, the layout the HIP side exports: samples[3*nN][c+1][n] (set-major: short
+ * 0..nN-1, mid, long; last byte of a sample = its flag), state[6][n] = next short / mid / long,
+ * index short / mid / long. */
+void gofo_knn_export(const gofo_knn *m, uint8_t *samples, uint8_t *state)
+{
+    size_t n = (size_t)m->h * m->w;
+    int nN = m->p.nsamples, ndata = m->c + 1;
+    for (size_t i = 0; i < n; i++) {
+        for (int s = 0; s < 3 * nN; s++)
+            for (int b = 0; b < ndata; b++)
+                samples[((size_t)s * ndata + b) * n + i] = m->model[(i * 3 * nN + s) * ndata + b];
+        for (int k = 0; k < 3; k++) {
+            state[(size_t)k * n + i] = m->next[i * 3 + k];
+            state[(size_t)(3 + k) * n + i] = m->index[i * 3 + k];
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------- */
 /* Whole path, steps 1-3 of GOFPID.detect  [REF pipeline.py:461-476]          */
 /* Used for end-to-end parity and as the timed CPU baseline ("port").         */
 /* ------------------------------------------------------------------------- */
@@ -671,12 +927,13 @@ typedef struct gofo_pipeline {
     int h, w, c;
     int blur_k;          /* 0 = no blur, else odd ksize (square); < 0: box of -blur_k */
     double blur_sigma;
-    int detector;        /* 0 = MOG2, 1 = FD                                  */
+    int detector;        /* 0 = MOG2, 1 = FD, 2 = KNN                         */
     double fd_thr;
     int n_morph;
     int morph_op[8];
     int morph_k[8];      /* rect size                                         */
     gofo_mog2 *mog2;
+    gofo_knn *knn;
     uint8_t *blurred, *prev, *m0, *m1, *tmp;
     int has_prev;
     int threads;
@@ -708,6 +965,7 @@ gofo_pipeline *gofo_pipeline_create(int h, int w, int c, int blur_k, double blur
     p->m1 = (uint8_t *)malloc(n);
     p->tmp = (uint8_t *)malloc(n);
     p->mog2 = detector == 0 ? gofo_mog2_create(h, w, c, NULL) : NULL;
+    p->knn = detector == 2 ? gofo_knn_create(h, w, c, NULL) : NULL;
     p->threads = threads;
     return p;
 }
@@ -717,6 +975,7 @@ void gofo_pipeline_destroy(gofo_pipeline *p)
     if (!p)
         return;
     gofo_mog2_destroy(p->mog2);
+    gofo_knn_destroy(p->knn);
     free(p->blurred);
     free(p->prev);
     free(p->m0);
@@ -771,6 +1030,8 @@ void gofo_pipeline_apply(gofo_pipeline *p, const uint8_t *frame, uint8_t *mask)
             int y0 = (int)((long)h * b / nt), y1 = (int)((long)h * (b + 1) / nt);
             mog2_rows(p->mog2, x, cur, y0, y1, alphaT, alpha1, prune);
         }
+    } else if (p->detector == 2) {
+        gofo_knn_apply(p->knn, x, cur);
     } else {
         gofo_fd_apply(x, p->prev, p->has_prev, p->fd_thr, h, w, c, cur);
         memcpy(p->prev, x, (size_t)h * w * c);
@@ -839,3 +1100,4 @@ double gofo_pipeline_mean_modes(const gofo_pipeline *p)
 }
 
 gofo_mog2 *gofo_pipeline_mog2(gofo_pipeline *p) { return p->mog2; }
+gofo_knn *gofo_pipeline_knn(gofo_pipeline *p) { return p->knn; }

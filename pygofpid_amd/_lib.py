@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("GOFPID_LIB") or os.path.join(_HERE, "csrc", "libgofpi
 
 OK, EINVAL, EHIP, ENOMEM, ENODEV = 0, 1, 2, 3, 4
 ERODE, DILATE = 0, 1
-DET_MOG2, DET_FD = 0, 1
+DET_MOG2, DET_FD, DET_KNN = 0, 1, 2
 BLUR_NONE, BLUR_GAUSS, BLUR_BOX = 0, 1, 2
 MAX_MODES, MAX_MORPH, MAX_KSIZE = 5, 8, 31
 
@@ -33,6 +33,12 @@ class Mog2Params(C.Structure):
         ("ct", C.c_float), ("tau", C.c_float),
         ("detect_shadows", C.c_int), ("shadow_value", C.c_int),
     ]
+
+
+class KnnParams(C.Structure):
+    _fields_ = [("history", C.c_int), ("nsamples", C.c_int), ("dist2_threshold", C.c_float),
+                ("knn", C.c_int), ("tau", C.c_float), ("detect_shadows", C.c_int),
+                ("shadow_value", C.c_int)]
 
 
 class MorphOp(C.Structure):
@@ -107,6 +113,15 @@ SIGNATURES = {
     "gof_pipeline_apply_host": (C.c_int, [C.c_void_p, _u8p, _u8p]),
     "gof_pipeline_apply_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "gof_pipeline_mog2": (C.c_void_p, [C.c_void_p]),
+    "gof_pipeline_knn": (C.c_void_p, [C.c_void_p]),
+    "gof_knn_default_params": (None, [C.POINTER(KnnParams)]),
+    "gof_knn_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(KnnParams),
+                                 C.POINTER(C.c_void_p)]),
+    "gof_knn_destroy": (None, [C.c_void_p]),
+    "gof_knn_apply_host": (C.c_int, [C.c_void_p, _u8p, _u8p]),
+    "gof_knn_apply_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "gof_knn_nframes": (C.c_int, [C.c_void_p]),
+    "gof_knn_export": (C.c_int, [C.c_void_p, _u8p, _u8p]),
     "gof_pipeline_set_convert": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "gof_pipeline_mean_modes": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "gof_pipeline_apply_host_many": (C.c_int, [C.c_void_p, _u8p, _u8p, C.c_int]),

@@ -99,6 +99,35 @@ struct gof_mog2 {
     }
 };
 
+struct gof_knn {
+    gof_ctx *ctx = nullptr;
+    gof_knn_params p{};
+    int streams = 0, h = 0, w = 0, c = 0;
+    int nframes = 0;
+    int short_counter = 0, mid_counter = 0, long_counter = 0;   // cv2's nShortCounter ... (class members)
+    size_t np = 0;            // plane pitch in dwords
+    size_t state_bytes = 0;
+    void *state = nullptr;    // [3 nN * ws] sample planes, then the next plane, then the index plane
+    hipStream_t last = nullptr;
+    DevBuf in, out, exp;
+    int ws() const { return c <= 3 ? 1 : 2; }
+    gofk::KnnState view() const
+    {
+        gofk::KnnState s;
+        s.samples = (uint32_t *)state;
+        s.next = s.samples + (size_t)3 * p.nsamples * ws() * np;
+        s.index = s.next + np;
+        s.np = np;
+        s.nN = p.nsamples;
+        s.knn = p.knn;
+        s.Tb = p.dist2_threshold;
+        s.tau = p.tau;
+        s.detect_shadows = p.detect_shadows;
+        s.shadow_value = p.shadow_value;
+        return s;
+    }
+};
+
 struct gof_fd {
     gof_ctx *ctx = nullptr;
     int streams = 0, h = 0, w = 0, c = 0;
@@ -121,6 +150,7 @@ struct gof_pipeline {
     std::vector<gofk::SeBits> sebits;
     gof_mog2 *mog2 = nullptr;
     gof_fd *fd = nullptr;
+    gof_knn *knn = nullptr;
     DevBuf in, out, blurred, m0, m1;
     // Host-frame batches are double-buffered (slot 0 = in / out, slot 1 = in1 / out1): the frames
     // of one batch go up on a copy stream while the kernels of the batch before run on the
@@ -771,6 +801,168 @@ int gof_mog2_state_copy(gof_mog2 *m, void *d_buf, int to_model)
 
 /* ---- frame differencing -------------------------------------------------- */
 
+// ---- KNN (pipeline.py:233-234) -------------------------------------------------------------
+void gof_knn_default_params(gof_knn_params *p)
+{
+    if (!p)
+        return;
+    p->history = 500;
+    p->nsamples = 7;
+    p->dist2_threshold = 20.0f * 20.0f;
+    p->knn = 2;   // cv2: max(1, cvRound(0.1 * nN * 3 + 0.40))
+    p->tau = 0.5f;
+    p->detect_shadows = 1;
+    p->shadow_value = 127;
+}
+
+int gof_knn_create(gof_ctx *ctx, int streams, int h, int w, int c, const gof_knn_params *p, gof_knn **out)
+{
+    if (!ctx || !out)
+        return fail(GOF_EINVAL, "NULL argument");
+    *out = nullptr;
+    int rc = check_geom(streams, h, w, c);
+    if (rc)
+        return rc;
+    gof_knn_params pp;
+    if (p)
+        pp = *p;
+    else
+        gof_knn_default_params(&pp);
+    if (pp.nsamples < 1 || pp.nsamples > 16 || pp.knn < 1 || pp.history < 1 || pp.shadow_value < 0 ||
+        pp.shadow_value > 255)
+        return fail(GOF_EINVAL, "bad KNN parameters (nsamples in [1,16], knn >= 1, history >= 1)");
+    gof_knn *k = new (std::nothrow) gof_knn;
+    if (!k)
+        return fail(GOF_ENOMEM, "host allocation failed");
+    k->ctx = ctx;
+    k->p = pp;
+    k->streams = streams;
+    k->h = h;
+    k->w = w;
+    k->c = c;
+    const size_t n = (size_t)streams * h * w;
+    k->np = (n + 63) & ~(size_t)63;
+    k->state_bytes = ((size_t)3 * pp.nsamples * k->ws() + 2) * k->np * sizeof(uint32_t);
+    GOF_HIP(hipSetDevice(ctx->device));
+    hipError_t e = hipMalloc(&k->state, k->state_bytes);
+    if (e != hipSuccess) {
+        const size_t b = k->state_bytes;
+        delete k;
+        return fail(GOF_ENOMEM, "hipMalloc(%zu B of KNN samples): %s", b, hipGetErrorString(e));
+    }
+    // cv2 starts from an all-zero model with every flag clear; complete before create returns
+    e = hipMemsetAsync(k->state, 0, k->state_bytes, ctx->stream);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        (void)hipFree(k->state);
+        delete k;
+        return fail(GOF_EHIP, "zero-filling the KNN model: %s", hipGetErrorString(e));
+    }
+    *out = k;
+    return GOF_OK;
+}
+
+void gof_knn_destroy(gof_knn *k)
+{
+    if (!k)
+        return;
+    (void)hipSetDevice(k->ctx->device);
+    if (k->last && k->last != k->ctx->stream)
+        (void)hipStreamSynchronize(k->last);
+    (void)hipStreamSynchronize(k->ctx->stream);
+    if (k->state)
+        (void)hipFree(k->state);
+    k->in.release();
+    k->out.release();
+    k->exp.release();
+    delete k;
+}
+
+int gof_knn_nframes(const gof_knn *k) { return k ? k->nframes : -1; }
+
+// cv2's BackgroundSubtractorKNNImpl::apply, the scalar part: frame count, learning rate
+// 1 / min(2 n, history) in double, the three cycle lengths, the counters (this frame's values go to
+// the kernel, the members advance) [OPENCV-RECALL]; restated identically in oracle/gof_oracle.c
+static gofk::KnnFrame knn_next_frame(gof_knn *k)
+{
+    k->nframes++;
+    const double lr = 1.0 / (double)std::min(2 * k->nframes, k->p.history);
+    const int nN = k->p.nsamples;
+    const int Kshort = (int)(log(0.7) / log(1 - lr)) + 1;
+    const int Kmid = (int)(log(0.4) / log(1 - lr)) - Kshort + 1;
+    const int Klong = (int)(log(0.1) / log(1 - lr)) - Kshort - Kmid + 1;
+    gofk::KnnFrame f;
+    f.n_short = Kshort / nN + 1;
+    f.n_mid = Kmid / nN + 1;
+    f.n_long = Klong / nN + 1;
+    f.short_counter = k->short_counter;
+    f.mid_counter = k->mid_counter;
+    f.long_counter = k->long_counter;
+    f.frame_no = (uint32_t)k->nframes;
+    if (++k->short_counter >= f.n_short)
+        k->short_counter = 0;
+    if (++k->mid_counter >= f.n_mid)
+        k->mid_counter = 0;
+    if (++k->long_counter >= f.n_long)
+        k->long_counter = 0;
+    return f;
+}
+
+int gof_knn_apply_dev(gof_knn *k, const void *d_frames, void *d_masks, void *stream)
+{
+    if (!k || !d_frames || !d_masks)
+        return fail(GOF_EINVAL, "NULL argument");
+    GOF_HIP(hipSetDevice(k->ctx->device));
+    hipStream_t s = pick(k->ctx, stream);
+    if (k->last && k->last != s)
+        GOF_HIP(hipStreamSynchronize(k->last));   // the model is a recurrence: one stream at a time
+    k->last = s;
+    const gofk::KnnFrame f = knn_next_frame(k);
+    GOF_HIP(gofk::knn_apply((const uint8_t *)d_frames, (uint8_t *)d_masks, k->view(), k->streams, k->h, k->w,
+                            k->c, f, s));
+    return GOF_OK;
+}
+
+int gof_knn_apply_host(gof_knn *k, const uint8_t *frames, uint8_t *masks)
+{
+    if (!k || !frames || !masks)
+        return fail(GOF_EINVAL, "NULL argument");
+    GOF_HIP(hipSetDevice(k->ctx->device));
+    const size_t npx = (size_t)k->streams * k->h * k->w;
+    int rc;
+    if ((rc = k->in.reserve(npx * k->c)) || (rc = k->out.reserve(npx)))
+        return rc;
+    hipStream_t s = k->ctx->stream;
+    GOF_HIP(hipMemcpyAsync(k->in.p, frames, npx * k->c, hipMemcpyHostToDevice, s));
+    if ((rc = gof_knn_apply_dev(k, k->in.p, k->out.p, nullptr)))
+        return rc;
+    GOF_HIP(hipMemcpyAsync(masks, k->out.p, npx, hipMemcpyDeviceToHost, s));
+    GOF_HIP(hipStreamSynchronize(s));
+    return GOF_OK;
+}
+
+int gof_knn_export(gof_knn *k, uint8_t *samples, uint8_t *state)
+{
+    if (!k || !samples || !state)
+        return fail(GOF_EINVAL, "NULL argument");
+    GOF_HIP(hipSetDevice(k->ctx->device));
+    hipStream_t s = k->ctx->stream;
+    if (k->last && k->last != s)
+        GOF_HIP(hipStreamSynchronize(k->last));
+    const size_t n = (size_t)k->streams * k->h * k->w;
+    const size_t nb_s = (size_t)3 * k->p.nsamples * (k->c + 1) * n, nb_t = 6 * n;
+    int rc;
+    if ((rc = k->exp.reserve(nb_s + nb_t)))
+        return rc;
+    uint8_t *d = (uint8_t *)k->exp.p;
+    GOF_HIP(gofk::knn_export(k->view(), k->c, n, d, d + nb_s, s));
+    GOF_HIP(hipMemcpyAsync(samples, d, nb_s, hipMemcpyDeviceToHost, s));
+    GOF_HIP(hipMemcpyAsync(state, d + nb_s, nb_t, hipMemcpyDeviceToHost, s));
+    GOF_HIP(hipStreamSynchronize(s));
+    return GOF_OK;
+}
+
 int gof_fd_create(gof_ctx *ctx, int streams, int h, int w, int c, double threshold, gof_fd **out)
 {
     if (!ctx || !out)
@@ -1152,7 +1344,7 @@ int gof_pipeline_create(gof_ctx *ctx, const gof_pipeline_desc *desc, gof_pipelin
         return rc;
     if (desc->n_morph < 0 || desc->n_morph > GOF_MAX_MORPH)
         return fail(GOF_EINVAL, "n_morph must be in [0, %d]", GOF_MAX_MORPH);
-    if (desc->detector != GOF_DET_MOG2 && desc->detector != GOF_DET_FD)
+    if (desc->detector != GOF_DET_MOG2 && desc->detector != GOF_DET_FD && desc->detector != GOF_DET_KNN)
         return fail(GOF_EINVAL, "Unknown method for foreground detection");
     if (desc->blur != GOF_BLUR_NONE && desc->blur != GOF_BLUR_GAUSS && desc->blur != GOF_BLUR_BOX)
         return fail(GOF_EINVAL, "unknown blur kind %d", desc->blur);
@@ -1199,6 +1391,10 @@ int gof_pipeline_create(gof_ctx *ctx, const gof_pipeline_desc *desc, gof_pipelin
         if ((rc = gof_mog2_create(ctx, desc->streams, desc->h, desc->w, desc->c, &desc->mog2,
                                   &p->mog2)))
             return bail(rc);
+    } else if (desc->detector == GOF_DET_KNN) {
+        // cv.createBackgroundSubtractorKNN() as the reference calls it: all defaults (pipeline.py:233-234)
+        if ((rc = gof_knn_create(ctx, desc->streams, desc->h, desc->w, desc->c, nullptr, &p->knn)))
+            return bail(rc);
     } else {
         if ((rc = gof_fd_create(ctx, desc->streams, desc->h, desc->w, desc->c, desc->fd_threshold,
                                 &p->fd)))
@@ -1221,6 +1417,7 @@ void gof_pipeline_destroy(gof_pipeline *p)
     (void)hipStreamSynchronize(p->ctx->stream);
     gof_mog2_destroy(p->mog2);
     gof_fd_destroy(p->fd);
+    gof_knn_destroy(p->knn);
     if (p->copy_stream) {
         (void)hipStreamSynchronize(p->copy_stream);
         (void)hipStreamDestroy(p->copy_stream);
@@ -1248,6 +1445,7 @@ void gof_pipeline_destroy(gof_pipeline *p)
 }
 
 gof_mog2 *gof_pipeline_mog2(gof_pipeline *p) { return p ? p->mog2 : nullptr; }
+gof_knn *gof_pipeline_knn(gof_pipeline *p) { return p ? p->knn : nullptr; }
 
 int gof_pipeline_set_convert(gof_pipeline *p, int c_in, int rgb_order)
 {
@@ -1353,6 +1551,11 @@ int gof_pipeline_apply_dev_many(gof_pipeline *p, const void *d_frames, void *d_m
             if (rfc && !written)   // (every MOG2 kernel writes them today; keep the contract explicit)
                 GOF_HIP(hipMemsetAsync(rfc, 0xFF, rf_chunk, s));   // "nothing is known to be zero"
         }
+    } else if (p->knn) {
+        // one launch per frame (the refresh counters and the draws' key advance per frame)
+        for (int t = 0; t < T; t++)
+            if ((rc = gof_knn_apply_dev(p->knn, x + (size_t)t * npx * d.c, det_out + (size_t)t * npx, s)))
+                return rc;
     } else if (fd_fused) {
         // blur + difference for up to kMaxT frames per launch; the blurred last frame is
         // handed from launch to launch in fd_prev

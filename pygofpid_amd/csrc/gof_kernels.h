@@ -145,6 +145,28 @@ hipError_t mog2_mode_soa(const Mog2State &st, int c, int mode, size_t n, float *
 hipError_t cvt_gray(const uint8_t *src, uint8_t *dst, int n_img, int h, int w, int c, bool rgb,
                     hipStream_t s);
 
+// ---- K-nearest-neighbours subtractor (gof_knn.hip) ---------------------------------------
+// Model in HBM, pitch np >= n_img * h * w dwords: samples = 3 nN sample planes (x 2 for 4-channel
+// frames): a pixel's sample is ONE dword (channel bytes + the flag in byte 3); next / index: a dword
+// per pixel, bytes (short, mid, long).
+struct KnnState {
+    uint32_t *samples, *next, *index;
+    size_t np;
+    int nN, knn;
+    float Tb, tau;
+    int detect_shadows, shadow_value;
+};
+// per-frame scalars, computed on the host as cv2 does (gof_api.cpp knn_next_frame)
+struct KnnFrame {
+    int short_counter, mid_counter, long_counter;   // counters of this frame
+    int n_short, n_mid, n_long;                     // cycle lengths of this frame
+    uint32_t frame_no;                              // 1-based frame count: key of the update draws
+};
+hipError_t knn_apply(const uint8_t *frame, uint8_t *mask, const KnnState &st, int n_img, int h, int w, int c,
+                     const KnnFrame &f, hipStream_t s);
+// byte planes for parity tests: d_samples[3 nN][c + 1][n], d_state[6][n] (device buffers)
+hipError_t knn_export(const KnnState &st, int c, size_t n, uint8_t *d_samples, uint8_t *d_state, hipStream_t s);
+
 // ---- blob extraction (gof_blobs.hip) ----------------------------------------------------
 // One entry per border (crack cycle): exact shoelace sums of the border polygon, pixel
 // changes along it (= its number of contour points), bounding box.

@@ -1,0 +1,292 @@
+// K-nearest-neighbours background subtractor for gfx950: what GOFPID(frg_detect='KNN') runs in
+// place of cv.createBackgroundSubtractorKNN().apply(X) [REF pygofpid/pipeline.py:233-234, :470].
+//
+// cv2's model and rule [OPENCV-RECALL bgfg_KNN.cpp], restated in oracle/gof_oracle.c (gofo_knn_*):
+// per pixel three sets (short / mid / long term) of nN samples, a sample = the pixel's channel
+// bytes + a flag byte; background = at least kNN flagged samples within dist2Threshold, shadow =
+// that many flagged samples passing the chromaticity test, else foreground; the sets are refreshed
+// at staggered times, each pixel drawing its slot of the next cycle.  cv2 draws with rand() inside
+// a row-parallel loop -- its own output is not reproducible -- so the draw here is a counter-based
+// hash of (pixel, frame, set), the same function in the oracle: kernel and oracle agree bit for bit
+// (masks and every model byte); against cv2 itself only the statistics can.
+//
+// Layout in HBM: one lane owns one pixel; every sample of every pixel is ONE dword (channel bytes
+// + the flag in byte 3; two dwords for 4-channel frames), sample s of all pixels is a plane, so a
+// wave reads a sample as one coalesced 256-B segment.  The check scans the planes in cv2's order
+// and stops as soon as every pixel of the wave is decided: a wave of settled background reads 2-3
+// of the 21 planes (cv2's early `return 1`, wave-uniform).  HBM-bound: 4 B per sample examined.
+#include "gof_kernels.h"
+
+namespace gofk {
+
+namespace {
+
+__device__ __forceinline__ uint32_t knn_draw(uint32_t pixel, uint32_t frame, uint32_t set)
+{
+    // oracle/gof_oracle.c gofo_knn_draw: 31 bits from (pixel, frame, set)
+    uint32_t x = pixel * 0x9E3779B1u ^ (frame * 0x85EBCA77u + set * 0xC2B2AE3Du);
+    x ^= x >> 16;
+    x *= 0x7FEB352Du;
+    x ^= x >> 15;
+    x *= 0x846CA68Bu;
+    x ^= x >> 16;
+    return x >> 1;
+}
+
+struct KnnArgs {
+    const uint8_t *frame;    // [n_img][h][w][C]
+    uint8_t *mask;           // [n_img][h][w]
+    uint32_t *samples;       // [3 nN][WS] planes of pitch np (WS = 1 dword per sample, 2 for C = 4)
+    uint32_t *next, *index;  // planes: bytes (short, mid, long, 0) per pixel
+    size_t np, n;            // plane pitch, pixels
+    uint32_t hw;             // pixels per image (the draw is keyed on the pixel within its image)
+    int nN, knn;
+    float Tb, tau;
+    int detect_shadows, shadow_value;
+    int short_counter, mid_counter, long_counter;   // this frame's counters (before the increment)
+    int n_short, n_mid, n_long;                     // this frame's cycle lengths
+    uint32_t frame_no;                              // 1-based
+};
+
+template <int C>
+struct KnnSample {
+    float v[C];
+    bool flag;
+};
+
+template <int C>
+__device__ __forceinline__ KnnSample<C> knn_load(const uint32_t *samples, size_t np, int s, size_t pix)
+{
+    constexpr int WS = C <= 3 ? 1 : 2;
+    KnnSample<C> r;
+    const uint32_t w0 = samples[(size_t)s * WS * np + pix];
+    if (C <= 3) {
+#pragma unroll
+        for (int c = 0; c < C; c++)
+            r.v[c] = (float)((w0 >> (8 * c)) & 255u);
+        r.flag = (w0 >> 24) != 0;
+    } else {
+        const uint32_t w1 = samples[((size_t)s * WS + 1) * np + pix];
+#pragma unroll
+        for (int c = 0; c < C; c++)
+            r.v[c] = (float)((w0 >> (8 * (c & 3))) & 255u);
+        r.flag = (w1 & 255u) != 0;
+    }
+    return r;
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void knn_kernel(const KnnArgs a)
+{
+    constexpr int WS = C <= 3 ? 1 : 2;
+    const size_t pix0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const bool valid = pix0 < a.n;
+    const size_t pix = valid ? pix0 : a.n - 1;   // lanes past the end shadow the last pixel; stores masked
+    const uint8_t *px = a.frame + pix * C;
+    uint32_t dbytes = 0;
+    float data[C];
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+        const uint32_t b = px[c];
+        dbytes |= b << (8 * (c & 3));
+        data[c] = (float)b;
+    }
+    const int ns = 3 * a.nN;
+
+    // ---- _cvCheckPixelBackgroundNP, first loop: neighbours within Tb, flagged ones among them
+    int Pbf = 0, Pb = 0;
+    bool bg = false;
+    for (int s = 0; s < ns; s++) {
+        if (__builtin_amdgcn_ballot_w64(!bg) == 0)
+            break;   // every pixel of the wave has its kNN flagged neighbours: cv2's `return 1`
+        const KnnSample<C> m = knn_load<C>(a.samples, a.np, s, pix);
+        float dist2;
+        if (C == 3) {
+            const float d0 = m.v[0] - data[0], d1 = m.v[1] - data[1], d2 = m.v[2] - data[2];
+            dist2 = d0 * d0 + d1 * d1 + d2 * d2;
+        } else {
+            dist2 = 0.f;
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+                const float d = m.v[c] - data[c];
+                dist2 += d * d;
+            }
+        }
+        if (!bg && dist2 < a.Tb) {
+            Pbf++;
+            if (m.flag) {
+                Pb++;
+                if (Pb >= a.knn)
+                    bg = true;
+            }
+        }
+    }
+    const bool include = bg || Pbf >= a.knn;
+
+    // ---- second loop (not background): shadow = kNN flagged samples that explain the pixel as a
+    //      darker version of themselves; a flagged all-zero sample ends the test (cv2's `return 0`)
+    int result = bg ? 1 : 0;
+    if (a.detect_shadows && __builtin_amdgcn_ballot_w64(!bg) != 0) {
+        bool done = bg;
+        int Ps = 0;
+        for (int s = 0; s < ns; s++) {
+            if (__builtin_amdgcn_ballot_w64(!done) == 0)
+                break;
+            const KnnSample<C> m = knn_load<C>(a.samples, a.np, s, pix);
+            if (!done && m.flag) {
+                float num = 0.f, den = 0.f;
+#pragma unroll
+                for (int c = 0; c < C; c++) {
+                    num += data[c] * m.v[c];
+                    den += m.v[c] * m.v[c];
+                }
+                if (den == 0.f) {
+                    done = true;
+                } else if (num <= den && num >= a.tau * den) {
+                    const float al = num / den;
+                    float dist2a = 0.f;
+#pragma unroll
+                    for (int c = 0; c < C; c++) {
+                        const float dD = al * m.v[c] - data[c];
+                        dist2a += dD * dD;
+                    }
+                    if (dist2a < a.Tb * al * al) {
+                        Ps++;
+                        if (Ps >= a.knn) {
+                            result = 2;
+                            done = true;
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- _cvUpdatePixelBackgroundNP: long <- the mid set's oldest, mid <- the short set's oldest,
+    //      short <- this pixel (offsets taken before any of the three); new slots at a cycle's end
+    const uint32_t nx = a.next[pix], ix = a.index[pix];
+    uint32_t nS = nx & 255u, nM = (nx >> 8) & 255u, nL = (nx >> 16) & 255u;
+    uint32_t iS = ix & 255u, iM = (ix >> 8) & 255u, iL = (ix >> 16) & 255u;
+    const uint32_t img_pix = (uint32_t)(pix % a.hw);
+    const size_t oS = (size_t)iS * WS * a.np + pix, oM = (size_t)(iM + a.nN) * WS * a.np + pix,
+                 oL = (size_t)(iL + 2 * a.nN) * WS * a.np + pix;
+    const uint32_t last = (uint32_t)a.nN - 1u;
+    if (valid && nL == (uint32_t)a.long_counter) {
+#pragma unroll
+        for (int q = 0; q < WS; q++)
+            a.samples[oL + (size_t)q * a.np] = a.samples[oM + (size_t)q * a.np];
+        iL = iL >= last ? 0u : iL + 1u;
+    }
+    if (a.long_counter == a.n_long - 1)
+        nL = (knn_draw(img_pix, a.frame_no, 2u) % (uint32_t)a.n_long) & 255u;
+    if (valid && nM == (uint32_t)a.mid_counter) {
+#pragma unroll
+        for (int q = 0; q < WS; q++)
+            a.samples[oM + (size_t)q * a.np] = a.samples[oS + (size_t)q * a.np];
+        iM = iM >= last ? 0u : iM + 1u;
+    }
+    if (a.mid_counter == a.n_mid - 1)
+        nM = (knn_draw(img_pix, a.frame_no, 1u) % (uint32_t)a.n_mid) & 255u;
+    if (valid && nS == (uint32_t)a.short_counter) {
+        if (C <= 3) {
+            a.samples[oS] = dbytes | (include ? 1u << 24 : 0u);
+        } else {
+            a.samples[oS] = dbytes;
+            a.samples[oS + a.np] = include ? 1u : 0u;
+        }
+        iS = iS >= last ? 0u : iS + 1u;
+    }
+    if (a.short_counter == a.n_short - 1)
+        nS = (knn_draw(img_pix, a.frame_no, 0u) % (uint32_t)a.n_short) & 255u;
+    if (!valid)
+        return;
+    const uint32_t nx2 = nS | (nM << 8) | (nL << 16), ix2 = iS | (iM << 8) | (iL << 16);
+    if (nx2 != nx)
+        a.next[pix] = nx2;
+    if (ix2 != ix)
+        a.index[pix] = ix2;
+    a.mask[pix] = result == 0 ? (uint8_t)255 : (result == 1 ? (uint8_t)0 : (uint8_t)a.shadow_value);
+}
+
+// the model as byte planes for export: samples[3 nN][C + 1][n], state[6][n]
+template <int C>
+__global__ __launch_bounds__(256) void knn_export_kernel(const uint32_t *samples, const uint32_t *next,
+                                                         const uint32_t *index, size_t np, size_t n, int nN,
+                                                         uint8_t *out_samples, uint8_t *out_state)
+{
+    constexpr int WS = C <= 3 ? 1 : 2;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n)
+        return;
+    for (int s = 0; s < 3 * nN; s++) {
+        const uint32_t w0 = samples[(size_t)s * WS * np + i];
+        const uint32_t w1 = WS == 2 ? samples[((size_t)s * WS + 1) * np + i] : 0u;
+        for (int c = 0; c < C; c++)
+            out_samples[((size_t)s * (C + 1) + c) * n + i] = (uint8_t)(w0 >> (8 * (c & 3)));
+        out_samples[((size_t)s * (C + 1) + C) * n + i] = C <= 3 ? (uint8_t)(w0 >> 24) : (uint8_t)w1;
+    }
+    const uint32_t nx = next[i], ix = index[i];
+    for (int k = 0; k < 3; k++) {
+        out_state[(size_t)k * n + i] = (uint8_t)(nx >> (8 * k));
+        out_state[(size_t)(3 + k) * n + i] = (uint8_t)(ix >> (8 * k));
+    }
+}
+
+}  // namespace
+
+hipError_t knn_apply(const uint8_t *frame, uint8_t *mask, const KnnState &st, int n_img, int h, int w, int c,
+                     const KnnFrame &f, hipStream_t s)
+{
+    if (n_img < 1 || h < 1 || w < 1 || st.nN < 1 || st.nN > 16 || st.knn < 1 || !st.samples || !st.next ||
+        !st.index || f.n_short < 1 || f.n_mid < 1 || f.n_long < 1)
+        return hipErrorInvalidValue;
+    const size_t n = (size_t)n_img * h * w;
+    if (st.np < n || (n + 255) / 256 > 0x7fffffffull || (size_t)h * w > 0xffffffffull)
+        return hipErrorInvalidValue;
+    KnnArgs a;
+    a.frame = frame;
+    a.mask = mask;
+    a.samples = st.samples;
+    a.next = st.next;
+    a.index = st.index;
+    a.np = st.np;
+    a.n = n;
+    a.hw = (uint32_t)((size_t)h * w);
+    a.nN = st.nN;
+    a.knn = st.knn;
+    a.Tb = st.Tb;
+    a.tau = st.tau;
+    a.detect_shadows = st.detect_shadows;
+    a.shadow_value = st.shadow_value;
+    a.short_counter = f.short_counter;
+    a.mid_counter = f.mid_counter;
+    a.long_counter = f.long_counter;
+    a.n_short = f.n_short;
+    a.n_mid = f.n_mid;
+    a.n_long = f.n_long;
+    a.frame_no = f.frame_no;
+    const dim3 g((unsigned)((n + 255) / 256));
+    switch (c) {
+    case 1: hipLaunchKernelGGL(knn_kernel<1>, g, dim3(256), 0, s, a); break;
+    case 3: hipLaunchKernelGGL(knn_kernel<3>, g, dim3(256), 0, s, a); break;
+    case 4: hipLaunchKernelGGL(knn_kernel<4>, g, dim3(256), 0, s, a); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t knn_export(const KnnState &st, int c, size_t n, uint8_t *d_samples, uint8_t *d_state, hipStream_t s)
+{
+    if (n < 1 || n > st.np || !d_samples || !d_state)
+        return hipErrorInvalidValue;
+    const dim3 g((unsigned)((n + 255) / 256));
+    switch (c) {
+    case 1: hipLaunchKernelGGL(knn_export_kernel<1>, g, dim3(256), 0, s, st.samples, st.next, st.index, st.np, n, st.nN, d_samples, d_state); break;
+    case 3: hipLaunchKernelGGL(knn_export_kernel<3>, g, dim3(256), 0, s, st.samples, st.next, st.index, st.np, n, st.nN, d_samples, d_state); break;
+    case 4: hipLaunchKernelGGL(knn_export_kernel<4>, g, dim3(256), 0, s, st.samples, st.next, st.index, st.np, n, st.nN, d_samples, d_state); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace gofk

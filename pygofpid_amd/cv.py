@@ -5,6 +5,7 @@ GOFPID.detect (pygofpid/pipeline.py:461-476):
 
     cv.GaussianBlur(X, ksize, borderType)           pipeline.py:463-467
     cv.createBackgroundSubtractorMOG2().apply(X)    pipeline.py:232, 470
+    cv.createBackgroundSubtractorKNN().apply(X)     pipeline.py:233-234, 470
     cv.erode(mask, kernel) / cv.dilate(mask, kernel) pipeline.py:475
     cv.getStructuringElement(cv.MORPH_RECT, (5, 5))  pipeline.py:180, 184, 247
 
@@ -225,3 +226,72 @@ class BackgroundSubtractorMOG2:
 
 def createBackgroundSubtractorMOG2(history=500, varThreshold=16, detectShadows=True):
     return BackgroundSubtractorMOG2(history, varThreshold, detectShadows)
+
+
+class BackgroundSubtractorKNN:
+    """cv.createBackgroundSubtractorKNN() object [REF pygofpid/pipeline.py:233-234]: `.apply(X) ->
+    (H, W) uint8` in {0, 127, 255}.  cv2's model (three sets of 7 samples per pixel), rule and
+    refresh structure with cv2's defaults; the per-pixel refresh slots, which cv2 draws with rand()
+    in a row-parallel loop (its own masks differ run to run), come from a hash of (pixel, frame,
+    set): deterministic, and bit-identical to this repository's CPU restatement.  Parity with cv2
+    itself is unpinnable by construction."""
+
+    def __init__(self, history=500, dist2Threshold=400.0, detectShadows=True, device=None):
+        p = _lib.KnnParams()
+        _lib.load().gof_knn_default_params(C.byref(p))
+        p.history = int(history)
+        p.dist2_threshold = float(dist2Threshold)
+        p.detect_shadows = int(bool(detectShadows))
+        self._params = p
+        self._device = device
+        self._h = C.c_void_p()
+        self._shape = None
+        self._ctx = None
+
+    def _ensure(self, h, w, c):
+        if self._shape == (h, w, c):
+            return
+        self._free()     # cv2 re-initialises the model when the frame size or type changes
+        self._ctx = _lib.default_context(self._device)
+        _lib.check(_lib.load().gof_knn_create(self._ctx.handle, 1, h, w, c, C.byref(self._params),
+                                              C.byref(self._h)))
+        self._shape = (h, w, c)
+
+    def apply(self, image):
+        x = _lib.as_u8(image, "image")
+        x, h, w, c = _lib.hwc(x)
+        self._ensure(h, w, c)
+        out = np.empty((h, w), np.uint8)
+        _lib.check(_lib.load().gof_knn_apply_host(self._h, _lib.p8(x), _lib.p8(out)))
+        return out
+
+    def export_state(self):
+        """{"samples": (3 nsamples, c + 1, N) uint8 -- sets short, mid, long; last byte of a sample
+        = its flag --, "state": (6, N) uint8 = next short / mid / long slot, index short / mid / long}"""
+        if not self._h:
+            raise RuntimeError("no frame seen yet")
+        h, w, c = self._shape
+        return knn_export(self._h, h * w, c, self._params.nsamples)
+
+    def _free(self):
+        if getattr(self, "_h", None):
+            _lib.load().gof_knn_destroy(self._h)
+            self._h = C.c_void_p()
+            self._shape = None
+
+    def __del__(self):
+        try:
+            self._free()
+        except Exception:
+            pass
+
+
+def knn_export(handle, n, c, nsamples=7):
+    samples = np.empty((3 * nsamples, c + 1, n), np.uint8)
+    state = np.empty((6, n), np.uint8)
+    _lib.check(_lib.load().gof_knn_export(handle, _lib.p8(samples), _lib.p8(state)))
+    return {"samples": samples, "state": state, "nframes": _lib.load().gof_knn_nframes(handle)}
+
+
+def createBackgroundSubtractorKNN(history=500, dist2Threshold=400.0, detectShadows=True):
+    return BackgroundSubtractorKNN(history, dist2Threshold, detectShadows)

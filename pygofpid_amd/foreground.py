@@ -21,7 +21,7 @@ class ForegroundPipeline:
     streams : number of independent streams stepped per call
     blur : None | (kw, kh, sigma_x[, sigma_y])   -- Gaussian, REFLECT_101
            | ('box', kw, kh)                     -- cv.blur, REFLECT_101
-    detector : 'MOG2' | 'FD'
+    detector : 'MOG2' | 'FD' | 'KNN' (cv2 defaults)
     morph : list of (op, kernel) with op in {'erode', 'dilate'} and kernel a
         (kh, kw) array (non-zero = member)
     convert : None | 'BGR2GRAY' | 'RGB2GRAY' -- step 0 on the device [REF pipeline.py:458-459]:
@@ -58,6 +58,8 @@ class ForegroundPipeline:
             d.detector = _lib.DET_MOG2
         elif detector == "FD":
             d.detector = _lib.DET_FD
+        elif detector == "KNN":
+            d.detector = _lib.DET_KNN
         else:
             raise ValueError("Unknown method for foreground detection")
         if mog2_params is None:
@@ -264,6 +266,14 @@ class ForegroundPipeline:
                                                          C.byref(n)))
         k = min(n.value, capacity)
         return a[:k], b[:k]
+
+    def knn_state(self):
+        """Export the KNN model (host copies): see cv.BackgroundSubtractorKNN.export_state."""
+        from . import cv
+        k = _lib.load().gof_pipeline_knn(self._h)
+        if not k:
+            raise RuntimeError("not a KNN pipeline")
+        return cv.knn_export(C.c_void_p(k), self.streams * self.h * self.w, self.model_c)
 
     def mog2_state(self):
         """Export the model planes (host copies) -- parity tests / checkpoint."""

@@ -23,8 +23,9 @@ What runs where
 Deliberate deviations, all off the hot path:
   * dict / list defaults are copied per instance (the reference shares and
     mutates its mutable defaults, SURVEY.md section 5);
-  * 'KNN' and 'ViBe' detectors and the interactive `display_config` windows
-    are not built (NotImplementedError), see SURVEY.md section 2 rows 7, 8, 11.
+  * the 'ViBe' detector and the interactive `display_config` windows are not built
+    (NotImplementedError); 'KNN' keeps cv2's model and rule
+    but draws its refresh slots from a hash instead of rand() (cv.BackgroundSubtractorKNN).
 """
 import numpy as np
 
@@ -81,10 +82,12 @@ class GOFPID():
             self._frg_detect_mth = cv.createBackgroundSubtractorMOG2()
         elif self.frg_detect == 'FD':
             self._frg_detect_mth = FrameDifferencing()
-        elif self.frg_detect in ('KNN', 'ViBe'):
+        elif self.frg_detect == 'KNN':
+            self._frg_detect_mth = cv.createBackgroundSubtractorKNN()
+        elif self.frg_detect == 'ViBe':
             raise NotImplementedError(
-                "frg_detect=%r is outside the MI355X foreground path (MOG2 and FD are built)"
-                % self.frg_detect)
+                "frg_detect='ViBe' is outside the MI355X foreground path (MOG2, KNN and FD are built): a "
+                "per-pixel Python loop driven by one sequential RandomState (reference segmentation.py:73-181)")
         else:
             raise ValueError('Unknown method for foreground detection')
 
@@ -235,7 +238,7 @@ class GOFPID():
                 return None
         else:
             blur = None
-        if self.frg_detect not in ('MOG2', 'FD'):
+        if self.frg_detect not in ('MOG2', 'FD', 'KNN'):
             return None
         morph = []
         for d in self.mat_morph or []:

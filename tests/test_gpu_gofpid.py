@@ -86,9 +86,9 @@ def test_gofpid_blur(G, cv, oracle, size, blur):
 
 
 @pytest.mark.parametrize("size", [(32, 20), (20, 32, 1), (32, 20, 3)])
-@pytest.mark.parametrize("frg_detect", ['MOG2', 'FD'])
+@pytest.mark.parametrize("frg_detect", ['MOG2', 'KNN', 'FD'])
 def test_gofpid_frgdetect(G, oracle, size, frg_detect):
-    """reference :98-109 for the two detectors in scope"""
+    """reference :98-109 for the three detectors built (ViBe raises NotImplementedError)"""
     gofpid = G(frg_detect=frg_detect, post_filter=post_filter.copy()).initialize()
     np.random.seed(17)
     h, w = size[:2]

@@ -666,3 +666,70 @@ def test_c_abi_error_codes():
     assert lib.gof_morph_dev(ctx.handle, 0, t.data_ptr(), t.data_ptr(), 1, 8, 8, None, 3, 3,
                              None) == _lib.EINVAL
     assert lib.gof_strerror(_lib.EHIP) == b"HIP runtime error"
+
+
+# ---- KNN (cv.createBackgroundSubtractorKNN, reference pipeline.py:233-234) ------------------
+
+def _assert_knn_state_equal(got, want):
+    assert got["samples"].shape == want["samples"].shape and got["state"].shape == want["state"].shape
+    assert np.array_equal(got["state"], want["state"])          # refresh slots and write indices
+    assert np.array_equal(got["samples"], want["samples"])      # every sample byte and flag
+
+
+@pytest.mark.parametrize("shape", [(32, 20), (20, 32, 1), (32, 20, 3), (6, 5, 4), (1, 1, 3), (67, 131, 3)])
+def test_knn_uniform_noise(cv, oracle, shape):
+    """The reference's own KNN case (tests/test_pipeline.py:98-109: uniform noise, 5 frames; more here):
+    masks and the whole sample model -- bytes, flags, slots, indices -- equal the CPU restatement.
+    (Parity with cv2 itself is unpinnable: its slots come from rand() in a row-parallel loop.)"""
+    gpu, ref = cv.createBackgroundSubtractorKNN(), oracle.KNN()
+    for f in uniform_noise_frames(shape, 14, seed=5):
+        got, want = gpu.apply(f), ref.apply(f)
+        assert got.shape == tuple(shape[:2]) and np.array_equal(got, want)
+    _assert_knn_state_equal(gpu.export_state(), ref.export())
+
+
+@pytest.mark.parametrize("c", [1, 3])
+def test_knn_clip_masks_and_state(cv, oracle, c):
+    """Static background + noise + moving objects + shadow patches through the learning-rate ramp
+    into long cycles (slots drawn, all three sets refreshed at their own times): background, shadow
+    and foreground all occur; masks and model equal the oracle frame by frame."""
+    h, w = 72, 100
+    clip = Clip(h, w, c, seed=8, n_objects=3)
+    gpu, ref = cv.createBackgroundSubtractorKNN(), oracle.KNN()
+    seen = set()
+    for t in range(120):
+        f = clip.frame(t)
+        got, want = gpu.apply(f), ref.apply(f)
+        assert np.array_equal(got, want), (t, int((got != want).sum()))
+        seen |= set(np.unique(got).tolist())
+        if t in (3, 40, 119):
+            _assert_knn_state_equal(gpu.export_state(), ref.export())
+    assert seen == {0, 127, 255}
+
+
+def test_knn_pipeline_streams_and_1080p(oracle):
+    """KNN inside the pipeline (blur -> KNN -> erode -> dilate), two streams, several frames per
+    call; and one 1080p stream: masks equal the oracle pipeline, the model equals per stream."""
+    from pygofpid_amd.foreground import ForegroundPipeline
+    h, w, c, S = 60, 88, 3, 2
+    clips = [Clip(h, w, c, seed=20 + s, n_objects=2) for s in range(S)]
+    gpu = ForegroundPipeline((h, w, c), streams=S, detector="KNN")
+    refs = [oracle.Pipeline(h, w, c, detector="KNN") for _ in range(S)]
+    for r in range(4):
+        frames = np.stack([np.stack([cl.frame(5 * r + i) for cl in clips]) for i in range(5)])
+        got = gpu.apply_many(frames)
+        for i in range(5):
+            for s in range(S):
+                assert np.array_equal(got[i, s], refs[s].apply(frames[i, s])), (r, i, s)
+    st = gpu.knn_state()
+    n = h * w
+    for s in range(S):
+        want = refs[s].export()
+        assert np.array_equal(st["samples"][:, :, s * n:(s + 1) * n], want["samples"])
+        assert np.array_equal(st["state"][:, s * n:(s + 1) * n], want["state"])
+    h, w = 1080, 1920
+    clip = Clip(h, w, 3, seed=2, n_objects=4)
+    gpu, ref = ForegroundPipeline((h, w, 3), detector="KNN"), oracle.Pipeline(h, w, 3, detector="KNN")
+    for t in range(6):
+        f = clip.frame(t)
+        assert np.array_equal(gpu.apply(f), ref.apply(f)), t
