@@ -208,6 +208,12 @@ int make_taps(int kw, int kh, double sx, double sy, gofk::Taps *t)
     t->nkx = kw;
     t->nky = kh;
     t->box_scale = 0.0;
+    // the detector kernels can take the 3x3 form themselves when the horizontal taps are bytes
+    // (a degenerate sigma gives [0, 256, 0], which goes through the generic blur instead)
+    t->fused3_ok = kw == 3 && kh == 3 && t->kx[0] < 256 && t->kx[1] < 256 && t->kx[2] < 256;
+    for (int j = 0; j < 3; j++)
+        t->vky[j] = kh == 3 ? t->ky[j] : 0;
+    t->vround = 32768u;
     return GOF_OK;
 }
 
@@ -222,6 +228,14 @@ int make_box(int kw, int kh, gofk::Taps *t)
     t->nkx = kw;
     t->nky = kh;
     t->box_scale = 1.0 / ((double)kw * (double)kh);
+    // 3x3: the fused form ((S + 4) * 7282) >> 16 -- accepted only if it reproduces
+    // rint(double(S) * box_scale) for every possible sum (it does; the loop is the proof)
+    t->fused3_ok = kw == 3 && kh == 3;
+    t->vky[0] = t->vky[1] = t->vky[2] = 7282u;
+    t->vround = 4u * 7282u;
+    for (uint32_t S = 0; t->fused3_ok && S <= 9u * 255u; S++)
+        if (((S * 7282u + t->vround) >> 16) != (uint32_t)std::nearbyint((double)S * t->box_scale))
+            t->fused3_ok = false;
     return GOF_OK;
 }
 
@@ -1361,14 +1375,15 @@ int gof_pipeline_create(gof_ctx *ctx, const gof_pipeline_desc *desc, gof_pipelin
         if ((rc = make_taps(desc->blur_kw, desc->blur_kh, desc->blur_sigma_x, desc->blur_sigma_y,
                             &p->taps)))
             return bail(rc);
-        // fused into the MOG2 kernel: 3x3, horizontal taps that fit a byte (a degenerate
-        // sigma gives [0, 256, 0], which goes through the generic blur instead)
-        p->fuse_blur3 = desc->detector == GOF_DET_MOG2 && p->taps.nkx == 3 && p->taps.nky == 3 &&
-                        p->taps.kx[0] < 256 && p->taps.kx[1] < 256 && p->taps.kx[2] < 256;
-        p->fuse_fd3 = desc->detector == GOF_DET_FD;   // geometry / taps: fd_frames_supported()
+        // fused into the detector kernel when the taps allow (Taps::fused3_ok)
+        p->fuse_blur3 = desc->detector == GOF_DET_MOG2 && p->taps.fused3_ok;
+        p->fuse_fd3 = desc->detector == GOF_DET_FD && p->taps.fused3_ok;   // + geometry: fd_frames_supported()
     } else if (desc->blur == GOF_BLUR_BOX) {
         if ((rc = make_box(desc->blur_kw, desc->blur_kh, &p->taps)))
             return bail(rc);
+        // cv.blur 3x3 (what the reference's tests configure, tests/test_pipeline.py:68-75) likewise
+        p->fuse_blur3 = desc->detector == GOF_DET_MOG2 && p->taps.fused3_ok;
+        p->fuse_fd3 = desc->detector == GOF_DET_FD && p->taps.fused3_ok;
     }
     bool all_rect = desc->n_morph > 0;
     p->chain.n = desc->n_morph;

@@ -72,6 +72,14 @@ struct Taps {
     // 0: 8.8 fixed-point taps, out = (sum + 2^15) >> 16.  != 0: normalised box
     // filter (all taps 1), out = rint(double(sum) * box_scale) as cv.blur does.
     double box_scale;
+    // What the kernels that fuse a 3x3 blur into the detector compute (fused3_ok):
+    //   out = (sum_j vky[j] * (sum_i kx[i] * p) + vround) >> 16
+    // Gaussian: vky = ky, vround = 2^15.  3x3 box: kx = (1,1,1), vky = 7282 (= ceil(2^16 / 9)),
+    // vround = 4 * 7282, i.e. ((S + 4) * 7282) >> 16 = floor((S + 4) / 9) = rint(S / 9) for
+    // every 9-pixel sum S <= 2295 (no ties at an odd area; checked exhaustively by the host).
+    uint32_t vky[3];
+    uint32_t vround;
+    bool fused3_ok;
 };
 
 struct SeBits {            // structuring element, bit dx of rows[dy] = member

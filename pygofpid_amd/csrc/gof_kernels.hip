@@ -55,7 +55,7 @@ struct FdFramesArgs {
     uint8_t *rowflags;        // as Mog2FramesArgs::rowflags (or NULL)
     size_t frame_stride, mask_stride;
     int H, W, T, has_prev, ithr, flag_pitch;
-    uint32_t kxw, ky012;
+    uint32_t kxw, vky0, vky1, vround;   // (as Mog2FramesArgs)
 };
 
 template <int C, int NT>   // NT: frames staged per launch (1 for the per-frame call, else kMaxT)
@@ -91,9 +91,9 @@ __global__ __launch_bounds__(256) void fd_frames_kernel(const FdFramesArgs a)
     TapPatterns<C> taps;
     taps.build(valid ? x : x0, W, ft.sx0, ft.mis0, a.kxw);
     uint32_t wa = (uint32_t)(wave * ROWD) * 4u + (uint32_t)taps.A;
-    uint32_t half = 32768u;
+    uint32_t half = a.vround;
     asm volatile("" : "+v"(half));
-    const uint32_t ky[3] = {a.ky012 & 1023u, (a.ky012 >> 10) & 1023u, a.ky012 >> 20};
+    const uint32_t ky[3] = {a.vky0, a.vky1, a.vky0};
     __syncthreads();
 
     uint8_t *mp = a.mask + pix;
@@ -900,8 +900,7 @@ bool fd_frames_supported(const uint8_t *frame, int n_img, int h, int w, int c, c
 {
     // byte taps whose folded outer pair fits a byte, at least two columns, and every
     // staged row of every frame at the same offset mod 4 (see mog2_apply)
-    return t.nkx == 3 && t.nky == 3 && t.box_scale == 0.0 && t.ky[0] == t.ky[2] && t.kx[0] < 256 && t.kx[1] < 256 &&
-           t.kx[2] < 256 && t.kx[0] + t.kx[2] <= 255 && w > 1 && ((size_t)w * c) % 4 == 0 &&
+    return t.fused3_ok && t.vky[0] == t.vky[2] && t.kx[0] + t.kx[2] <= 255 && w > 1 && ((size_t)w * c) % 4 == 0 &&
            ((size_t)h * w * c) % 4 == 0 && ((size_t)n_img * h * w * c) % 4 == 0 &&
            (uintptr_t)frame % 4 == 0 && (c == 1 || c == 3 || c == 4);
 }
@@ -928,7 +927,9 @@ hipError_t fd_frames_apply(const uint8_t *frame, uint8_t *mask, const uint32_t *
     a.ithr = ithr;
     a.flag_pitch = rowflag_pitch(w);
     a.kxw = (uint32_t)t.kx[0] | ((uint32_t)t.kx[1] << 8) | ((uint32_t)t.kx[2] << 16);
-    a.ky012 = t.ky[0] | (t.ky[1] << 10) | (t.ky[2] << 20);
+    a.vky0 = t.vky[0];
+    a.vky1 = t.vky[1];
+    a.vround = t.vround;
     dim3 g = grid3(w, h, n_img, TW, TH);
 #define GOF_LAUNCH_FD(CC)                                                                   \
     do {                                                                                    \

@@ -29,7 +29,8 @@ __global__ __launch_bounds__(64 * TR, (!MULTI && ALN && C <= 3) ? 8 : 1) void mo
                                                    uint8_t *__restrict__ modes, size_t np, int H,
                                                    int W, int T_arg, size_t frame_stride,
                                                    size_t mask_stride, Mog2Consts k, uint32_t kx012,
-                                                   uint32_t ky012, uint8_t *__restrict__ rowflags,
+                                                   uint32_t vky0, uint32_t vky1, uint32_t vky2, uint32_t vround,
+                                                   uint8_t *__restrict__ rowflags,
                                                    int flag_pitch, const uint8_t *frame_end)
 {
     constexpr int F = 2 + C;  // floats per mode
@@ -162,7 +163,9 @@ __global__ __launch_bounds__(64 * TR, (!MULTI && ALN && C <= 3) ? 8 : 1) void mo
 
     // the three horizontal taps as bytes (< 256 each, the launcher checks)
     const uint32_t kxw = (kx012 & 1023u) | (((kx012 >> 10) & 1023u) << 8) | ((kx012 >> 20) << 16);
-    const int ky[3] = {(int)(ky012 & 1023), (int)((ky012 >> 10) & 1023), (int)(ky012 >> 20)};
+    // vertical multipliers and rounding constant of the fused 3x3 form (Taps::vky / vround: the
+    // Gaussian's taps and 2^15, or the box filter's 7282 and 4 * 7282)
+    const uint32_t ky[3] = {vky0, vky1, vky2};
     // byte offsets (within a staged row) of the left / centre / right pixel
     const int xc = valid ? x : sx0;
     const int pl = (reflect1(xc - 1, W) - sx0) * C, pc = (xc - sx0) * C,
@@ -205,7 +208,7 @@ __global__ __launch_bounds__(64 * TR, (!MULTI && ALN && C <= 3) ? 8 : 1) void mo
             uint32_t acc[C];
 #pragma unroll
             for (int c = 0; c < C; c++)
-                acc[c] = 32768u;
+                acc[c] = vround;
 #pragma unroll
             for (int j = 0; j < 3; j++) {
                 uint32_t L, Cn, R;
@@ -243,7 +246,7 @@ __global__ __launch_bounds__(64 * TR, (!MULTI && ALN && C <= 3) ? 8 : 1) void mo
                     const uint32_t g = __builtin_amdgcn_perm(R, t, 0x0C000100u | ((4u + c) << 16));
                     // 24-bit multiply-add: the sums are < 2^16, the taps < 2^9 (full-rate
                     // v_mad_u32_u24 instead of the quarter-rate 32-bit multiply)
-                    acc[c] = __umul24((uint32_t)ky[j], __builtin_amdgcn_udot4(g, kxw, 0u, false)) + acc[c];
+                    acc[c] = __umul24(ky[j], __builtin_amdgcn_udot4(g, kxw, 0u, false)) + acc[c];
                 }
             }
 #pragma unroll
@@ -377,13 +380,11 @@ hipError_t mog2_apply(const uint8_t *frame, uint8_t *mask, const Mog2State &st, 
     if (n_img < 1 || h < 1 || w < 1 || (h + TH - 1) / TH > 65535 || n_img > 65535 ||
         st.np < (size_t)n_img * h * w || k.nmix < 1 || k.nmix > kMaxModes || T < 1 || T > kMaxT)
         return hipErrorInvalidValue;
-    if (fused_blur3 && (t.nkx != 3 || t.nky != 3 || t.kx[0] > 255 || t.kx[1] > 255 || t.kx[2] > 255))
-        return hipErrorInvalidValue;   // the fused horizontal pass uses byte taps
-    uint32_t kx = 0, ky = 0;
-    if (fused_blur3) {
+    if (fused_blur3 && !t.fused3_ok)
+        return hipErrorInvalidValue;   // the fused horizontal pass uses byte taps (Taps::fused3_ok)
+    uint32_t kx = 0;
+    if (fused_blur3)
         kx = t.kx[0] | (t.kx[1] << 10) | (t.kx[2] << 20);
-        ky = t.ky[0] | (t.ky[1] << 10) | (t.ky[2] << 20);
-    }
     // frames [T][n_img][h][w][c], masks [T][n_img][h][w]
     const size_t fstride = (size_t)n_img * h * w * c, mstride = (size_t)n_img * h * w;
     if (frame_bytes < (size_t)T * fstride)
@@ -397,7 +398,7 @@ hipError_t mog2_apply(const uint8_t *frame, uint8_t *mask, const Mog2State &st, 
     // (its tap patterns add the outer taps where the border reflection folds them)
     // (its variance clamp is one v_med3_f32, which needs var_min <= var_max; anything else
     // takes the general kernel below)
-    if (aln && T > 1 && w > 1 && t.kx[0] + t.kx[2] <= 255 && t.ky[0] == t.ky[2] &&
+    if (aln && T > 1 && w > 1 && t.kx[0] + t.kx[2] <= 255 && t.vky[0] == t.vky[2] &&
         k.var_min <= k.var_max) {   // the multi-frame launch proper
         const hipError_t e = mog2_frames_launch(frame, mask, st, n_img, h, w, c, T, k, t, s, rowflags);
         if (e != hipErrorNotSupported)
@@ -415,7 +416,7 @@ hipError_t mog2_apply(const uint8_t *frame, uint8_t *mask, const Mog2State &st, 
     }();
 #define GOF_LAUNCH_MOG2_(CC, BB, MM, AA)                                                         \
     hipLaunchKernelGGL((mog2_kernel<CC, BB, MM, AA>), g, dim3(256), 0, s, frame, mask,           \
-                       st.planes, st.modes, st.np, h, w, T, fstride, mstride, k, kx, ky, rowflags,      \
+                       st.planes, st.modes, st.np, h, w, T, fstride, mstride, k, kx, t.vky[0], t.vky[1], t.vky[2], t.vround, rowflags, \
                        rowflag_pitch(w), frame_end)
 #define GOF_LAUNCH_MOG2(CC, BB)                                                                  \
     do {                                                                                         \
@@ -423,11 +424,11 @@ hipError_t mog2_apply(const uint8_t *frame, uint8_t *mask, const Mog2State &st, 
             const dim3 gr = grid3(w, h, n_img, TW, tile_rows);                                   \
             if (tile_rows == 2)                                                                  \
                 hipLaunchKernelGGL((mog2_kernel<3, true, false, true, 2>), gr, dim3(128), 0, s, frame, mask, \
-                                   st.planes, st.modes, st.np, h, w, T, fstride, mstride, k, kx, ky,  \
+                                   st.planes, st.modes, st.np, h, w, T, fstride, mstride, k, kx, t.vky[0], t.vky[1], t.vky[2], t.vround,  \
                                    rowflags, rowflag_pitch(w), frame_end);                       \
             else                                                                                 \
                 hipLaunchKernelGGL((mog2_kernel<3, true, false, true, 8>), gr, dim3(512), 0, s, frame, mask, \
-                                   st.planes, st.modes, st.np, h, w, T, fstride, mstride, k, kx, ky,  \
+                                   st.planes, st.modes, st.np, h, w, T, fstride, mstride, k, kx, t.vky[0], t.vky[1], t.vky[2], t.vround,  \
                                    rowflags, rowflag_pitch(w), frame_end);                       \
         } else if (T == 1 && aln)                                                                \
             GOF_LAUNCH_MOG2_(CC, BB, false, (BB));                                               \

@@ -39,7 +39,7 @@ struct Mog2FramesArgs {
     size_t np, frame_stride, mask_stride;
     int H, W, T;
     uint32_t kxw;     // horizontal taps as bytes (k0 | k1 << 8 | k2 << 16)
-    uint32_t ky012;   // vertical taps, 10 bits each
+    uint32_t vky0, vky1, vround;   // vertical multipliers (rows 0 / 2 share one) and rounding constant (Taps::vky)
     uint8_t *rowflags;   // [image][row][tile column] bytes, bit t = frame t's mask not all zero there (or NULL)
     int flag_pitch;
     Mog2Consts k;
@@ -140,10 +140,10 @@ __global__ __launch_bounds__(256, C <= 3 ? GOF_FRAMES_WAVES : 1) void mog2_frame
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
     uint32_t wa = (uint32_t)(wave * ROWD) * 4u + (uint32_t)taps.A;   // window address, current frame
-    uint32_t half = 32768u;
+    uint32_t half = a.vround;
     float var_max_v = a.k.var_max;   // (the clamp takes one scalar operand, var_min)
     asm volatile("" : "+v"(half), "+v"(var_max_v));   // kept in registers, not re-materialised per use
-    const uint32_t ky[3] = {a.ky012 & 1023u, (a.ky012 >> 10) & 1023u, a.ky012 >> 20};
+    const uint32_t ky[3] = {a.vky0, a.vky1, a.vky0};
 
     // blurred pixel of the current frame as floats (batch: the nine LDS reads issued
     // back to back -- not in the general loop, which has the whole mixture in registers)
@@ -301,8 +301,8 @@ hipError_t mog2_frames_launch(const uint8_t *frame, uint8_t *mask, const Mog2Sta
                               uint8_t *rowflags)
 {
     if (n_img < 1 || h < 1 || w < 2 || T < 2 || T > kMaxT || (h + TH - 1) / TH > 65535 || n_img > 65535 ||
-        st.np < (size_t)n_img * h * w || t.nkx != 3 || t.nky != 3 || t.kx[0] + t.kx[2] > 255 ||
-        t.kx[1] > 255 || t.ky[0] != t.ky[2] || !(k.var_min <= k.var_max))
+        st.np < (size_t)n_img * h * w || !t.fused3_ok || t.kx[0] + t.kx[2] > 255 ||
+        t.vky[0] != t.vky[2] || !(k.var_min <= k.var_max))
         return hipErrorInvalidValue;
     Mog2FramesArgs a;
     a.frame = frame;
@@ -316,7 +316,9 @@ hipError_t mog2_frames_launch(const uint8_t *frame, uint8_t *mask, const Mog2Sta
     a.W = w;
     a.T = T;
     a.kxw = (uint32_t)t.kx[0] | ((uint32_t)t.kx[1] << 8) | ((uint32_t)t.kx[2] << 16);
-    a.ky012 = t.ky[0] | (t.ky[1] << 10) | (t.ky[2] << 20);
+    a.vky0 = t.vky[0];
+    a.vky1 = t.vky[1];
+    a.vround = t.vround;
     a.rowflags = rowflags;
     a.flag_pitch = rowflag_pitch(w);
     a.k = k;
