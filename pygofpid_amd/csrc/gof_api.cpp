@@ -1382,8 +1382,9 @@ int gof_pipeline_create(gof_ctx *ctx, const gof_pipeline_desc *desc, gof_pipelin
         if ((rc = make_box(desc->blur_kw, desc->blur_kh, &p->taps)))
             return bail(rc);
         // cv.blur 3x3 (what the reference's tests configure, tests/test_pipeline.py:68-75) likewise
-        p->fuse_blur3 = desc->detector == GOF_DET_MOG2 && p->taps.fused3_ok;
-        p->fuse_fd3 = desc->detector == GOF_DET_FD && p->taps.fused3_ok;
+        const bool no_box_fusion = getenv("GOF_NO_FUSE_BOX") != nullptr;   // A/B knob (profiles/)
+        p->fuse_blur3 = desc->detector == GOF_DET_MOG2 && p->taps.fused3_ok && !no_box_fusion;
+        p->fuse_fd3 = desc->detector == GOF_DET_FD && p->taps.fused3_ok && !no_box_fusion;
     }
     bool all_rect = desc->n_morph > 0;
     p->chain.n = desc->n_morph;
@@ -1496,7 +1497,17 @@ int gof_pipeline_apply_dev_many(gof_pipeline *p, const void *d_frames, void *d_m
 
     // step 0 (pipeline.py:458-459), when switched on: BGR / RGB -> grey, on the device
     const uint8_t *x = (const uint8_t *)d_frames;
-    if (p->cvt_c) {
+    // ... fused into the MOG2 kernel's staging when the 3x3 blur is (no grey image in HBM, one
+    // detector launch); otherwise its own kernel
+    bool cvt_fused = false;
+    static const bool no_step0_fusion = getenv("GOF_NO_FUSE_STEP0") != nullptr;   // A/B knob (profiles/)
+    if (p->cvt_c && p->mog2 && p->fuse_blur3 && d.c == 1 && !no_step0_fusion) {
+        gofk::Mog2Consts kc{};
+        kc.var_min = p->mog2->p.var_min;
+        kc.var_max = p->mog2->p.var_max;
+        cvt_fused = gofk::mog2_convert_supported(x, d.streams, d.h, d.w, p->cvt_c, p->taps, kc);
+    }
+    if (p->cvt_c && !cvt_fused) {
         if ((rc = p->gray.reserve((size_t)T * npx)))
             return rc;
         GOF_HIP(gofk::cvt_gray(x, (uint8_t *)p->gray.p, T * d.streams, d.h, d.w, p->cvt_c, p->cvt_rgb, s));
@@ -1555,10 +1566,18 @@ int gof_pipeline_apply_dev_many(gof_pipeline *p, const void *d_frames, void *d_m
             uint8_t *rfc = rf ? rf + (size_t)(t0 / gofk::kMaxT) * rf_chunk : nullptr;
             bool written = false;
             p->mog2->last = s;
-            hipError_t e = gofk::mog2_apply(x + (size_t)t0 * npx * d.c, det_out + (size_t)t0 * npx,
-                                            p->mog2->view(), d.streams, d.h, d.w, d.c, tn, k,
-                                            p->fuse_blur3, p->taps, s, rfc, &written,
-                                            (size_t)(T - t0) * npx * d.c);
+            hipError_t e;
+            if (cvt_fused) {
+                e = gofk::mog2_convert_apply(x + (size_t)t0 * npx * p->cvt_c, det_out + (size_t)t0 * npx,
+                                             p->mog2->view(), d.streams, d.h, d.w, p->cvt_c, p->cvt_rgb, tn, k,
+                                             p->taps, s, rfc);
+                written = rfc != nullptr;
+            } else {
+                e = gofk::mog2_apply(x + (size_t)t0 * npx * d.c, det_out + (size_t)t0 * npx,
+                                     p->mog2->view(), d.streams, d.h, d.w, d.c, tn, k,
+                                     p->fuse_blur3, p->taps, s, rfc, &written,
+                                     (size_t)(T - t0) * npx * d.c);
+            }
             if (e != hipSuccess) {
                 p->mog2->nframes -= tn;
                 return fail(GOF_EHIP, "mog2 launch: %s", hipGetErrorString(e));
@@ -1888,7 +1907,9 @@ int gof_pipeline_algorithmic_bytes(gof_pipeline *p, double mean_modes, int n_fra
     const double T = n_frames;
     // detector: every frame in and every mask out; the MOG2 model moves once per
     // launch of up to kMaxT frames (temporal blocking), FD state once per frame
-    double det = T * (d.c + 1.0);
+    // (a converting pipeline whose 3x3 blur is fused reads the colour frames in the detector kernel)
+    const bool cvt_fused = p->cvt_c && p->mog2 && p->fuse_blur3 && d.c == 1;
+    double det = T * ((cvt_fused ? p->cvt_c : d.c) + 1.0);
     if (p->mog2) {
         const double launches = (double)((n_frames + gofk::kMaxT - 1) / gofk::kMaxT);
         det += launches * 2.0 * (1.0 + 4.0 * (2 + d.c) * mean_modes);   // model read + write
@@ -1896,6 +1917,8 @@ int gof_pipeline_algorithmic_bytes(gof_pipeline *p, double mean_modes, int n_fra
         det += T * 2.0 * d.c;                                  // X_{t-1} read, X_t kept
     }
     double tot = det;
+    if (p->cvt_c && !cvt_fused)
+        tot += T * (p->cvt_c + 1.0);                           // step 0 as its own kernel
     if (d.blur != GOF_BLUR_NONE && !p->fuse_blur3)
         tot += T * 2.0 * d.c;                                  // blurred image written + read
     const int morph_kernels = d.n_morph == 0 ? 0 : (p->chain_ok ? 1 : d.n_morph);

@@ -114,8 +114,19 @@ hipError_t mog2_apply(const uint8_t *frame, uint8_t *mask, const Mog2State &st, 
                       hipStream_t s, uint8_t *rowflags, bool *rowflags_written, size_t frame_bytes);
 
 // the multi-frame launch behind mog2_apply (gof_mog2_frames.hip); mog2_apply decides when it applies
+// src_c != 0: step 0 fused -- the frames have src_c (3 | 4) channels, BGR order unless src_rgb, and are
+// converted to grey inside the kernel (c == 1); then T == 1 is accepted as well
 hipError_t mog2_frames_launch(const uint8_t *frame, uint8_t *mask, const Mog2State &st, int n_img, int h,
                               int w, int c, int T, const Mog2Consts &k, const Taps &t, hipStream_t s,
+                              uint8_t *rowflags, int src_c = 0, bool src_rgb = false);
+// can mog2_convert_apply take these frames?  (3x3 byte taps, symmetric vertical multipliers,
+// every staged row of every colour frame at the same offset mod 4, var_min <= var_max)
+bool mog2_convert_supported(const uint8_t *frame, int n_img, int h, int w, int src_c, const Taps &t,
+                            const Mog2Consts &k);
+// steps 0-2 in one kernel: colour frames [T][n_img][h][w][src_c] -> grey -> 3x3 blur -> MOG2 (one-channel
+// model st), T <= kMaxT
+hipError_t mog2_convert_apply(const uint8_t *frame, uint8_t *mask, const Mog2State &st, int n_img, int h, int w,
+                              int src_c, bool src_rgb, int T, const Mog2Consts &k, const Taps &t, hipStream_t s,
                               uint8_t *rowflags);
 
 hipError_t fd_apply(const uint8_t *cur, const uint8_t *prev, bool has_prev, int ithr,

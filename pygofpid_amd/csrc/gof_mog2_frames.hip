@@ -44,6 +44,7 @@ struct Mog2FramesArgs {
     int flag_pitch;
     Mog2Consts k;
     uint32_t taps[kTapTableDwords];   // tap_table(kxw, C): the lanes' blur patterns
+    int g0, g1, g2;                   // CS != 0: luma weights of source channels 0 / 1 / 2 (cvt_gray's, 14-bit)
 };
 
 // (7 waves per SIMD for BGR: the issue-bound launch needs every one of them; the float4
@@ -51,13 +52,21 @@ struct Mog2FramesArgs {
 #ifndef GOF_FRAMES_WAVES
 #define GOF_FRAMES_WAVES 7   // (A/B knob of profiles/: waves per SIMD the register allocation aims at)
 #endif
-template <int C>
-__global__ __launch_bounds__(256, C <= 3 ? GOF_FRAMES_WAVES : 1) void mog2_frames_kernel(const Mog2FramesArgs a)
+// CS: channels of the frames as they arrive when step 0 (cv.cvtColor to grey, pipeline.py:458-459)
+// is fused into the staging -- the colour rows are staged raw, converted to a grey tile in LDS
+// (cvt_gray's integer, one pass of the workgroup), and the kernel proceeds as the one-channel
+// kernel on that tile: no grey image ever exists in HBM.  CS = 0: frames arrive with C channels.
+// NT: frames staged per launch (kMaxT, or 1 for the per-frame call of a converting pipeline).
+constexpr int kGrayRowD = 20;   // dwords per grey tile row: 66 px + the 12-byte window's reach
+template <int C, int CS = 0, int NT = kMaxT>
+__global__ __launch_bounds__(256, (C <= 3 && CS != 4) ? GOF_FRAMES_WAVES : 1) void mog2_frames_kernel(const Mog2FramesArgs a)
 {
     constexpr int F = 2 + C;
-    typedef FrameTiles<C> Tiles;
-    constexpr int ROWD = Tiles::ROWD, TILE = Tiles::TILE;
-    __shared__ uint32_t tiles[Tiles::LDS_DWORDS];
+    static_assert(CS == 0 || C == 1, "the conversion produces one channel");
+    typedef FrameTiles<(CS ? CS : C), NT> Tiles;
+    constexpr int ROWD = CS ? kGrayRowD : Tiles::ROWD, TILE = (TH + 2) * ROWD;
+    __shared__ uint32_t tiles[NT * TILE];
+    __shared__ uint32_t ctiles[CS ? Tiles::LDS_DWORDS : 1];   // the raw colour tiles (CS != 0)
 
     const int H = a.H, W = a.W, T = a.T;
     const int lane = threadIdx.x & 63;
@@ -75,7 +84,7 @@ __global__ __launch_bounds__(256, C <= 3 ? GOF_FRAMES_WAVES : 1) void mog2_frame
     // ---- stage the tiles of all T frames (loads now, LDS writes after the model
     //      loads are in flight); borders are resolved at read time ----
     Tiles ft;
-    uint32_t raw[kMaxT][2][Tiles::NDW];
+    uint32_t raw[NT][2][Tiles::NDW];
     ft.load(a.frame, a.frame_stride, H, W, T, img, x0, y0, wave, lane, raw);
 
     // ---- model: mode count + mode 0 speculatively, the rest only if present ----
@@ -100,14 +109,15 @@ __global__ __launch_bounds__(256, C <= 3 ? GOF_FRAMES_WAVES : 1) void mog2_frame
     TapPatterns<C> taps;
     {
         typedef const Mog2FramesArgs __attribute__((address_space(4))) *ArgsPtr0;
-        taps.load(valid ? x : x0, W, ft.sx0, ft.mis0, ((ArgsPtr0)__builtin_amdgcn_kernarg_segment_ptr())->taps);
+        // (a grey tile row starts with the pixel itself: no offset within its first dword)
+        taps.load(valid ? x : x0, W, ft.sx0, CS ? 0 : ft.mis0, ((ArgsPtr0)__builtin_amdgcn_kernarg_segment_ptr())->taps);
     }
     // slots 1.. are loaded only if some pixel of the wave has them; otherwise slot 1
     // starts empty (the single-mode loops may fill it) and slots 2.. stay untouched
     // until the general loop is entered
     // the staged rows go to LDS before the further modes are asked for: the 16 staging
     // registers are free again by then (settled waves, four in five, load no further mode)
-    Tiles::store(tiles, wave, lane, raw);
+    Tiles::store(CS ? ctiles : tiles, wave, lane, raw);
     const bool multi_in = __builtin_amdgcn_ballot_w64(nmodes > 1) != 0;
     if (multi_in) {
         // slot m is fetched by the whole wave if any of its pixels has it (the lines travel anyway;
@@ -138,6 +148,28 @@ __global__ __launch_bounds__(256, C <= 3 ? GOF_FRAMES_WAVES : 1) void mog2_frame
     // model loads above stay in flight across it: __syncthreads() would wait for them, and a
     // settled wave would then sit out the second round trip of a neighbour that fetches five modes).
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (CS) {
+        // step 0 on the staged tiles: every pixel of every staged row of every frame once --
+        // (B * g0 + G * g1 + R * g2 + 2^13) >> 14, gray_kernel's statement -- into the grey tile
+        const int npx = ((x0 + TW + 1) < W ? (x0 + TW + 1) : W) - ft.sx0;   // staged pixels per row (<= 66)
+        const uint8_t *cb = (const uint8_t *)ctiles + ft.mis0;
+        uint8_t *gb = (uint8_t *)tiles;
+        // a wave takes every fourth staged row (all frames), a lane pixel `lane` of it and, for the
+        // first lanes, pixel 64 + lane: no index arithmetic beyond two running offsets
+        for (int rr = wave; rr < NT * (TH + 2); rr += 4) {
+            const uint8_t *crow = cb + (size_t)rr * Tiles::ROWD * 4;
+            uint8_t *grow = gb + (size_t)rr * ROWD * 4;
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+                const int px = lane + 64 * half;
+                if (px < npx) {
+                    const uint8_t *q = crow + px * CS;
+                    grow[px] = (uint8_t)((q[0] * a.g0 + q[1] * a.g1 + q[2] * a.g2 + (1 << 13)) >> 14);
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
 
     uint32_t wa = (uint32_t)(wave * ROWD) * 4u + (uint32_t)taps.A;   // window address, current frame
     uint32_t half = a.vround;
@@ -298,9 +330,13 @@ __global__ __launch_bounds__(256, C <= 3 ? GOF_FRAMES_WAVES : 1) void mog2_frame
 // byte, the vertical taps are symmetric, 2 <= T <= kMaxT and w > 1.
 hipError_t mog2_frames_launch(const uint8_t *frame, uint8_t *mask, const Mog2State &st, int n_img, int h,
                               int w, int c, int T, const Mog2Consts &k, const Taps &t, hipStream_t s,
-                              uint8_t *rowflags)
+                              uint8_t *rowflags, int src_c, bool src_rgb)
 {
-    if (n_img < 1 || h < 1 || w < 2 || T < 2 || T > kMaxT || (h + TH - 1) / TH > 65535 || n_img > 65535 ||
+    // src_c != 0: the frames arrive with src_c (3 | 4) channels and are converted to grey inside the
+    // kernel (c == 1); T == 1 is taken too then (the per-frame kernel has no converting form)
+    if ((src_c != 0 && (c != 1 || (src_c != 3 && src_c != 4))) || (src_c == 0 && T < 2))
+        return hipErrorInvalidValue;
+    if (n_img < 1 || h < 1 || w < 2 || T < 1 || T > kMaxT || (h + TH - 1) / TH > 65535 || n_img > 65535 ||
         st.np < (size_t)n_img * h * w || !t.fused3_ok || t.kx[0] + t.kx[2] > 255 ||
         t.vky[0] != t.vky[2] || !(k.var_min <= k.var_max))
         return hipErrorInvalidValue;
@@ -310,7 +346,11 @@ hipError_t mog2_frames_launch(const uint8_t *frame, uint8_t *mask, const Mog2Sta
     a.planes = st.planes;
     a.modes = st.modes;
     a.np = st.np;
-    a.frame_stride = (size_t)n_img * h * w * c;
+    a.frame_stride = (size_t)n_img * h * w * (src_c ? src_c : c);
+    const int B2Y = 1868, G2Y = 9617, R2Y = 4899;   // (cvt_gray's weights, gof_kernels.hip)
+    a.g0 = src_rgb ? R2Y : B2Y;
+    a.g1 = G2Y;
+    a.g2 = src_rgb ? B2Y : R2Y;
     a.mask_stride = (size_t)n_img * h * w;
     a.H = h;
     a.W = w;
@@ -324,6 +364,19 @@ hipError_t mog2_frames_launch(const uint8_t *frame, uint8_t *mask, const Mog2Sta
     a.k = k;
     tap_table(a.kxw, c, a.taps);
     const dim3 g = grid3(w, h, n_img, TW, TH);
+    if (src_c) {
+        if (T == 1) {
+            if (src_c == 3)
+                hipLaunchKernelGGL((mog2_frames_kernel<1, 3, 1>), g, dim3(256), 0, s, a);
+            else
+                hipLaunchKernelGGL((mog2_frames_kernel<1, 4, 1>), g, dim3(256), 0, s, a);
+        } else if (src_c == 3) {
+            hipLaunchKernelGGL((mog2_frames_kernel<1, 3, kMaxT>), g, dim3(256), 0, s, a);
+        } else {
+            hipLaunchKernelGGL((mog2_frames_kernel<1, 4, kMaxT>), g, dim3(256), 0, s, a);
+        }
+        return hipGetLastError();
+    }
     switch (c) {
     case 1: hipLaunchKernelGGL(mog2_frames_kernel<1>, g, dim3(256), 0, s, a); break;
     case 3: hipLaunchKernelGGL(mog2_frames_kernel<3>, g, dim3(256), 0, s, a); break;
@@ -346,5 +399,24 @@ extern "C" int gof_debug_path_stats(unsigned long long *out)
     return (int)e;
 }
 #endif
+
+bool mog2_convert_supported(const uint8_t *frame, int n_img, int h, int w, int src_c, const Taps &t,
+                            const Mog2Consts &k)
+{
+    const size_t fstride = (size_t)n_img * h * w * src_c;
+    return (src_c == 3 || src_c == 4) && n_img >= 1 && h >= 1 && w > 1 && t.fused3_ok && t.kx[0] + t.kx[2] <= 255 &&
+           t.vky[0] == t.vky[2] && k.var_min <= k.var_max && ((size_t)w * src_c) % 4 == 0 && fstride % 4 == 0 &&
+           ((size_t)h * w * src_c) % 4 == 0 && (uintptr_t)frame % 4 == 0 && (h + TH - 1) / TH <= 65535 &&
+           n_img <= 65535;
+}
+
+hipError_t mog2_convert_apply(const uint8_t *frame, uint8_t *mask, const Mog2State &st, int n_img, int h, int w,
+                              int src_c, bool src_rgb, int T, const Mog2Consts &k, const Taps &t, hipStream_t s,
+                              uint8_t *rowflags)
+{
+    if (!mog2_convert_supported(frame, n_img, h, w, src_c, t, k))
+        return hipErrorNotSupported;
+    return mog2_frames_launch(frame, mask, st, n_img, h, w, 1, T, k, t, s, rowflags, src_c, src_rgb);
+}
 
 }  // namespace gofk

@@ -264,3 +264,48 @@ print("RCCL-REHEARSAL-OK")
                MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "RCCL-REHEARSAL-OK" in out.stdout, (out.stdout[-800:], out.stderr[-1500:])
+
+
+@pytest.mark.parametrize("shape,cin", [((60, 88), 3), ((61, 87), 3), ((40, 130), 4), ((1080, 1920), 3)])
+def test_convert_and_box_blur_fused_into_the_detector(oracle, shape, cin):
+    """Step 0 (cv.cvtColor to grey, reference pipeline.py:458-459) and cv.blur 3x3 (reference
+    tests/test_pipeline.py:68-75) inside the detector kernel: colour frames in, ONE detector launch per
+    step (the byte model of the pipeline counts no separate grey / blur pass for aligned frames), masks
+    equal the oracle's on oracle-converted frames for 1-frame and 8-frame calls; odd geometries take
+    the separate kernels and give the same masks."""
+    from pygofpid_amd.foreground import ForegroundPipeline
+    h, w = shape
+    nfr = 10 if h < 500 else 9
+    clip = Clip(h, w, 3, seed=7, n_objects=3)
+    rng = np.random.default_rng(2)
+
+    def frame(t):
+        f = clip.frame(t)
+        return f if cin == 3 else np.concatenate([f, rng.integers(0, 256, (h, w, 1), dtype=np.uint8)], axis=2)
+
+    frames = [frame(t) for t in range(nfr)]
+    grays = [oracle.cvt_gray(np.ascontiguousarray(f[:, :, :3]), rgb_order=False) for f in frames]
+    for blur, okw in (((3, 3, 4.0), dict(blur_k=3)), (("box", 3, 3), dict(blur_k=-3))):
+        pipe = ForegroundPipeline((h, w, cin), convert="BGR2GRAY", blur=blur)
+        ref = oracle.Pipeline(h, w, 1, **okw)
+        assert np.array_equal(pipe.apply(frames[0]), ref.apply(grays[0]))
+        got = pipe.apply_many(np.stack(frames[1:9]))
+        for i in range(8):
+            assert np.array_equal(got[i], ref.apply(grays[1 + i])), (blur, i)
+        if nfr > 9:
+            assert np.array_equal(pipe.apply(frames[9]), ref.apply(grays[9]))
+        tot, det = pipe.algorithmic_bytes(1.0, 8)
+        aligned = (w * cin) % 4 == 0 and (h * w * cin) % 4 == 0
+        if aligned:
+            assert tot - det == 8 * 2 * h * w        # beyond the detector: the one morphology launch only
+            assert det >= 8 * (cin + 1) * h * w      # and the detector reads the colour frames itself
+    # the box filter alone (no conversion) on colour frames: fused as well
+    pipe = ForegroundPipeline((h, w, 3), blur=("box", 3, 3))
+    ref = oracle.Pipeline(h, w, 3, blur_k=-3)
+    cf = [clip.frame(t) for t in range(9)]
+    assert np.array_equal(pipe.apply(cf[0]), ref.apply(cf[0]))
+    got = pipe.apply_many(np.stack(cf[1:9]))
+    for i in range(8):
+        assert np.array_equal(got[i], ref.apply(cf[1 + i]))
+    tot, det = pipe.algorithmic_bytes(1.0, 8)
+    assert tot - det == 8 * 2 * h * w
