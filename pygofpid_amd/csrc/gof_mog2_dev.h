@@ -144,22 +144,30 @@ __device__ __forceinline__ void row_store(void *row_base, unsigned byte_off, T v
     *(T __attribute__((address_space(1))) *)(b + byte_off) = v;
 }
 
+// the lane's column as it is wanted at an access: opaque, so that the scaled offsets (x 4, x 16) are
+// formed next to their use instead of living in registers of their own for the whole kernel
+__device__ __forceinline__ unsigned lane_col(unsigned xl)
+{
+    asm("" : "+v"(xl));
+    return xl;
+}
+
 template <int C>
 __device__ __forceinline__ void load_mode_vec_row(const float *mode, size_t np, size_t rowoff, unsigned xl,
                                                   float &var, float (&mu)[C])
 {
     if (C == 1) {
-        const f32x2 q = row_load<f32x2>((const float2 *)(mode + np) + rowoff, xl * 8u);
+        const f32x2 q = row_load<f32x2>((const float2 *)(mode + np) + rowoff, lane_col(xl) * 8u);
         var = q.x;
         mu[0] = q.y;
     } else {
-        const f32x4 q = row_load<f32x4>((const float4 *)(mode + np) + rowoff, xl * 16u);
+        const f32x4 q = row_load<f32x4>((const float4 *)(mode + np) + rowoff, lane_col(xl) * 16u);
         var = q.x;
         mu[0] = q.y;
         mu[1 % C] = q.z;
         mu[2 % C] = q.w;
         if (C == 4)
-            mu[3 % C] = row_load<float>(mode + 5 * np + rowoff, xl * 4u);
+            mu[3 % C] = row_load<float>(mode + 5 * np + rowoff, lane_col(xl) * 4u);
     }
 }
 
@@ -168,11 +176,11 @@ __device__ __forceinline__ void store_mode_vec_row(float *mode, size_t np, size_
                                                    const float (&mu)[C])
 {
     if (C == 1) {
-        row_store<f32x2>((float2 *)(mode + np) + rowoff, xl * 8u, f32x2{var, mu[0]});
+        row_store<f32x2>((float2 *)(mode + np) + rowoff, lane_col(xl) * 8u, f32x2{var, mu[0]});
     } else {
-        row_store<f32x4>((float4 *)(mode + np) + rowoff, xl * 16u, f32x4{var, mu[0], mu[1 % C], mu[2 % C]});
+        row_store<f32x4>((float4 *)(mode + np) + rowoff, lane_col(xl) * 16u, f32x4{var, mu[0], mu[1 % C], mu[2 % C]});
         if (C == 4)
-            row_store<float>(mode + 5 * np + rowoff, xl * 4u, mu[3 % C]);
+            row_store<float>(mode + 5 * np + rowoff, lane_col(xl) * 4u, mu[3 % C]);
     }
 }
 
