@@ -176,6 +176,16 @@ def test_state_shape_validation(tmp_path):
         b_ = ForegroundPipeline((h, w, c), mog2_params=p3)
         np.savez(str(tmp_path / "bad.npz"), geometry=np.array([1, h, w, c]), nmixtures=np.array(3), **bad)
         b_.load_state(str(tmp_path / "bad.npz"))
+    # a checkpoint of the FIRST format (planes padded to 5 modes, no 'nmixtures' key) written by a
+    # 3-mode pipeline still loads into a 3-mode pipeline (the modes it keeps are the first ones)
+    st3 = a.mog2_state()
+    pad = lambda x: np.concatenate([x, np.zeros((2,) + x.shape[1:], x.dtype)])
+    np.savez(str(tmp_path / "v1.npz"), geometry=np.array([1, h, w, c]), weight=pad(st3["weight"]),
+             var=pad(st3["var"]), mean=pad(st3["mean"]), modes=st3["modes"], nframes=st3["nframes"])
+    d = ForegroundPipeline((h, w, c), mog2_params=p3)
+    d.load_state(str(tmp_path / "v1.npz"))
+    f2 = Clip(h, w, c, seed=1).frame(2)
+    assert np.array_equal(a.apply(f2), d.apply(f2))
 
 
 @pytest.mark.parametrize("code", ["BGR2GRAY", "RGB2GRAY"])
