@@ -923,7 +923,8 @@ static gofk::KnnFrame knn_next_frame(gof_knn *k)
     return f;
 }
 
-int gof_knn_apply_dev(gof_knn *k, const void *d_frames, void *d_masks, void *stream)
+// (blur3: the pipeline's 3x3 blur runs inside the KNN kernel)
+static int knn_apply_frame(gof_knn *k, const void *d_frames, void *d_masks, void *stream, const gofk::Taps *blur3)
 {
     if (!k || !d_frames || !d_masks)
         return fail(GOF_EINVAL, "NULL argument");
@@ -934,8 +935,13 @@ int gof_knn_apply_dev(gof_knn *k, const void *d_frames, void *d_masks, void *str
     k->last = s;
     const gofk::KnnFrame f = knn_next_frame(k);
     GOF_HIP(gofk::knn_apply((const uint8_t *)d_frames, (uint8_t *)d_masks, k->view(), k->streams, k->h, k->w,
-                            k->c, f, s));
+                            k->c, f, s, blur3));
     return GOF_OK;
+}
+
+int gof_knn_apply_dev(gof_knn *k, const void *d_frames, void *d_masks, void *stream)
+{
+    return knn_apply_frame(k, d_frames, d_masks, stream, nullptr);
 }
 
 int gof_knn_apply_host(gof_knn *k, const uint8_t *frames, uint8_t *masks)
@@ -1526,7 +1532,11 @@ int gof_pipeline_apply_dev_many(gof_pipeline *p, const void *d_frames, void *d_m
         GOF_HIP(hipMemcpyAsync(p->in.p, x, (size_t)T * npx * d.c, hipMemcpyDeviceToDevice, s));
         x = (const uint8_t *)p->in.p;
     }
-    if (d.blur != GOF_BLUR_NONE && !p->fuse_blur3 && !fd_fused) {
+    // KNN: the 3x3 blur runs inside the KNN kernel when the frames are aligned (as the fused FD kernel)
+    static const bool no_knn_fusion = getenv("GOF_NO_FUSE_KNN_BLUR") != nullptr;   // A/B knob (profiles/)
+    const bool knn_fused = p->knn && d.blur != GOF_BLUR_NONE && p->taps.fused3_ok && !no_knn_fusion &&
+                           gofk::knn_blur3_supported(x, d.streams, d.h, d.w, d.c, p->taps);
+    if (d.blur != GOF_BLUR_NONE && !p->fuse_blur3 && !fd_fused && !knn_fused) {
         if ((rc = p->blurred.reserve((size_t)T * npx * d.c)))
             return rc;
         GOF_HIP(gofk::blur_sep_q8(x, (uint8_t *)p->blurred.p, T * d.streams, d.h, d.w, d.c, p->taps, s));
@@ -1588,7 +1598,8 @@ int gof_pipeline_apply_dev_many(gof_pipeline *p, const void *d_frames, void *d_m
     } else if (p->knn) {
         // one launch per frame (the refresh counters and the draws' key advance per frame)
         for (int t = 0; t < T; t++)
-            if ((rc = gof_knn_apply_dev(p->knn, x + (size_t)t * npx * d.c, det_out + (size_t)t * npx, s)))
+            if ((rc = knn_apply_frame(p->knn, x + (size_t)t * npx * d.c, det_out + (size_t)t * npx, s,
+                                      knn_fused ? &p->taps : nullptr)))
                 return rc;
     } else if (fd_fused) {
         // blur + difference for up to kMaxT frames per launch; the blurred last frame is
@@ -1919,7 +1930,7 @@ int gof_pipeline_algorithmic_bytes(gof_pipeline *p, double mean_modes, int n_fra
     double tot = det;
     if (p->cvt_c && !cvt_fused)
         tot += T * (p->cvt_c + 1.0);                           // step 0 as its own kernel
-    if (d.blur != GOF_BLUR_NONE && !p->fuse_blur3)
+    if (d.blur != GOF_BLUR_NONE && !p->fuse_blur3 && !(p->knn && p->taps.fused3_ok))
         tot += T * 2.0 * d.c;                                  // blurred image written + read
     const int morph_kernels = d.n_morph == 0 ? 0 : (p->chain_ok ? 1 : d.n_morph);
     tot += T * 2.0 * morph_kernels;                            // each reads a mask, writes a mask

@@ -181,8 +181,11 @@ struct KnnFrame {
     int n_short, n_mid, n_long;                     // cycle lengths of this frame
     uint32_t frame_no;                              // 1-based frame count: key of the update draws
 };
+// blur3 != NULL: the frames are blurred 3x3 (GaussianBlur / cv.blur, Taps::fused3_ok) inside the kernel;
+// the caller checks knn_blur3_supported first
 hipError_t knn_apply(const uint8_t *frame, uint8_t *mask, const KnnState &st, int n_img, int h, int w, int c,
-                     const KnnFrame &f, hipStream_t s);
+                     const KnnFrame &f, hipStream_t s, const Taps *blur3 = nullptr);
+bool knn_blur3_supported(const uint8_t *frame, int n_img, int h, int w, int c, const Taps &t);
 // byte planes for parity tests: d_samples[3 nN][c + 1][n], d_state[6][n] (device buffers)
 hipError_t knn_export(const KnnState &st, int c, size_t n, uint8_t *d_samples, uint8_t *d_state, hipStream_t s);
 

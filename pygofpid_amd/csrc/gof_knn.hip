@@ -15,7 +15,7 @@
 // wave reads a sample as one coalesced 256-B segment.  The check scans the planes in cv2's order
 // and stops as soon as every pixel of the wave is decided: a wave of settled background reads 2-3
 // of the 21 planes (cv2's early `return 1`, wave-uniform).  HBM-bound: 4 B per sample examined.
-#include "gof_kernels.h"
+#include "gof_mog2_dev.h"   // FrameTiles / TapPatterns: the staged-tile 3x3 blur front end the fused form borrows
 
 namespace gofk {
 
@@ -46,6 +46,10 @@ struct KnnArgs {
     int short_counter, mid_counter, long_counter;   // this frame's counters (before the increment)
     int n_short, n_mid, n_long;                     // this frame's cycle lengths
     uint32_t frame_no;                              // 1-based
+    // fused 3x3 blur (knn_blur3_kernel): geometry, tap table, vertical multipliers and rounding constant
+    int H, W;
+    uint32_t vky0, vky1, vround;
+    uint32_t taps[kTapTableDwords];
 };
 
 template <int C>
@@ -75,22 +79,13 @@ __device__ __forceinline__ KnnSample<C> knn_load(const uint32_t *samples, size_t
     return r;
 }
 
+// One pixel of cv2's KNNInvoker: check (background / shadow / foreground), refresh, new slots.
+// data / dbytes: the pixel's channels as floats / packed bytes; pix: its index in the planes;
+// valid == false: a lane that shadows a pixel (all of its stores are masked).
 template <int C>
-__global__ __launch_bounds__(256) void knn_kernel(const KnnArgs a)
+__device__ __forceinline__ void knn_pixel(const KnnArgs &a, size_t pix, bool valid, const float (&data)[C], uint32_t dbytes)
 {
     constexpr int WS = C <= 3 ? 1 : 2;
-    const size_t pix0 = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const bool valid = pix0 < a.n;
-    const size_t pix = valid ? pix0 : a.n - 1;   // lanes past the end shadow the last pixel; stores masked
-    const uint8_t *px = a.frame + pix * C;
-    uint32_t dbytes = 0;
-    float data[C];
-#pragma unroll
-    for (int c = 0; c < C; c++) {
-        const uint32_t b = px[c];
-        dbytes |= b << (8 * (c & 3));
-        data[c] = (float)b;
-    }
     const int ns = 3 * a.nN;
 
     // ---- _cvCheckPixelBackgroundNP, first loop: neighbours within Tb, flagged ones among them
@@ -208,6 +203,65 @@ __global__ __launch_bounds__(256) void knn_kernel(const KnnArgs a)
     a.mask[pix] = result == 0 ? (uint8_t)255 : (result == 1 ? (uint8_t)0 : (uint8_t)a.shadow_value);
 }
 
+template <int C>
+__global__ __launch_bounds__(256) void knn_kernel(const KnnArgs a)
+{
+    const size_t pix0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const bool valid = pix0 < a.n;
+    const size_t pix = valid ? pix0 : a.n - 1;   // lanes past the end shadow the last pixel; stores masked
+    const uint8_t *px = a.frame + pix * C;
+    uint32_t dbytes = 0;
+    float data[C];
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+        const uint32_t b = px[c];
+        dbytes |= b << (8 * (c & 3));
+        data[c] = (float)b;
+    }
+    knn_pixel<C>(a, pix, valid, data, dbytes);
+}
+
+// GaussianBlur / cv.blur 3x3 + KNN in one kernel [REF pipeline.py:463-470]: the staging and tap-pattern
+// front end of the MOG2 kernels (64 x 4 px tiles, one wave per row, rows staged raw, the blur as dot
+// products against per-lane tap patterns), then knn_pixel on the blurred pixel: the blurred frame never
+// exists in memory.  Aligned frames only (fd_frames_supported); anything else runs blur_kernel + knn_kernel.
+template <int C>
+__global__ __launch_bounds__(256) void knn_blur3_kernel(const KnnArgs a)
+{
+    typedef FrameTiles<C, 1> Tiles;
+    constexpr int ROWD = Tiles::ROWD;
+    __shared__ __attribute__((aligned(16))) uint32_t tiles[Tiles::LDS_DWORDS];
+    const int H = a.H, W = a.W;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH, img = blockIdx.z;
+    const int x = x0 + lane, y = y0 + wave;
+    Tiles ft;
+    uint32_t raw[1][2][Tiles::NDW];
+    ft.load(a.frame, 0, H, W, 1, img, x0, y0, wave, lane, raw);
+    const bool valid = y < H && x < W;
+    TapPatterns<C> taps;
+    {
+        typedef const KnnArgs __attribute__((address_space(4))) *ArgsPtr0;
+        taps.load(valid ? x : x0, W, ft.sx0, ft.mis0, ((ArgsPtr0)__builtin_amdgcn_kernarg_segment_ptr())->taps);
+    }
+    Tiles::store(tiles, wave, lane, raw);
+    __syncthreads();
+    const uint32_t ky[3] = {a.vky0, a.vky1, a.vky0};
+    uint32_t v[C];
+    taps.template blur<ROWD>(tiles, (uint32_t)(wave * ROWD) * 4u + (uint32_t)taps.A, ky, a.vround, false, v);
+    uint32_t dbytes = 0;
+    float data[C];
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+        dbytes |= v[c] << (8 * (c & 3));
+        data[c] = (float)v[c];
+    }
+    // a lane outside the image shadows the first pixel of its tile's row inside it (stores masked)
+    const size_t pix = (size_t)img * H * W + (size_t)(y < H ? y : H - 1) * W + (x < W ? x : x0);
+    knn_pixel<C>(a, pix, valid, data, dbytes);
+}
+
 // the model as byte planes for export: samples[3 nN][C + 1][n], state[6][n]
 template <int C>
 __global__ __launch_bounds__(256) void knn_export_kernel(const uint32_t *samples, const uint32_t *next,
@@ -235,7 +289,7 @@ __global__ __launch_bounds__(256) void knn_export_kernel(const uint32_t *samples
 }  // namespace
 
 hipError_t knn_apply(const uint8_t *frame, uint8_t *mask, const KnnState &st, int n_img, int h, int w, int c,
-                     const KnnFrame &f, hipStream_t s)
+                     const KnnFrame &f, hipStream_t s, const Taps *blur3)
 {
     if (n_img < 1 || h < 1 || w < 1 || st.nN < 1 || st.nN > 16 || st.knn < 1 || !st.samples || !st.next ||
         !st.index || f.n_short < 1 || f.n_mid < 1 || f.n_long < 1)
@@ -265,6 +319,26 @@ hipError_t knn_apply(const uint8_t *frame, uint8_t *mask, const KnnState &st, in
     a.n_mid = f.n_mid;
     a.n_long = f.n_long;
     a.frame_no = f.frame_no;
+    a.H = h;
+    a.W = w;
+    a.vky0 = a.vky1 = a.vround = 0;
+    if (blur3) {
+        // the 3x3 blur inside the kernel (the caller has checked knn_blur3_supported)
+        if (!knn_blur3_supported(frame, n_img, h, w, c, *blur3))
+            return hipErrorInvalidValue;
+        a.vky0 = blur3->vky[0];
+        a.vky1 = blur3->vky[1];
+        a.vround = blur3->vround;
+        tap_table((uint32_t)blur3->kx[0] | ((uint32_t)blur3->kx[1] << 8) | ((uint32_t)blur3->kx[2] << 16), c, a.taps);
+        const dim3 gb = grid3(w, h, n_img, TW, TH);
+        switch (c) {
+        case 1: hipLaunchKernelGGL(knn_blur3_kernel<1>, gb, dim3(256), 0, s, a); break;
+        case 3: hipLaunchKernelGGL(knn_blur3_kernel<3>, gb, dim3(256), 0, s, a); break;
+        case 4: hipLaunchKernelGGL(knn_blur3_kernel<4>, gb, dim3(256), 0, s, a); break;
+        default: return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     const dim3 g((unsigned)((n + 255) / 256));
     switch (c) {
     case 1: hipLaunchKernelGGL(knn_kernel<1>, g, dim3(256), 0, s, a); break;
@@ -273,6 +347,12 @@ hipError_t knn_apply(const uint8_t *frame, uint8_t *mask, const KnnState &st, in
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
+}
+
+bool knn_blur3_supported(const uint8_t *frame, int n_img, int h, int w, int c, const Taps &t)
+{
+    // as the fused frame-differencing kernel: byte taps, symmetric vertical multipliers, aligned rows / frames
+    return fd_frames_supported(frame, n_img, h, w, c, t) && (h + TH - 1) / TH <= 65535 && n_img <= 65535;
 }
 
 hipError_t knn_export(const KnnState &st, int c, size_t n, uint8_t *d_samples, uint8_t *d_state, hipStream_t s)

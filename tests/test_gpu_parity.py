@@ -707,11 +707,39 @@ def test_knn_clip_masks_and_state(cv, oracle, c):
     assert seen == {0, 127, 255}
 
 
+@pytest.mark.parametrize("geom", [(60, 88, 3), (45, 75, 3), (50, 132, 1), (33, 70, 4)])
+def test_knn_pipeline_streams(oracle, geom):
+    """KNN inside the pipeline (blur -> KNN -> erode -> dilate), two streams, several frames per call:
+    aligned rows take the kernel with the 3x3 blur inside (ragged tiles included), the others the
+    separate blur kernel; masks equal the oracle pipeline, the model equals per stream."""
+    from pygofpid_amd.foreground import ForegroundPipeline
+    h, w, c = geom
+    S = 2
+    clips = [Clip(h, w, c, seed=20 + s, n_objects=2) for s in range(S)]
+    gpu = ForegroundPipeline((h, w, c), streams=S, detector="KNN")
+    refs = [oracle.Pipeline(h, w, c, detector="KNN") for _ in range(S)]
+    for r in range(4):
+        frames = np.stack([np.stack([cl.frame(5 * r + i) for cl in clips]) for i in range(5)])
+        got = gpu.apply_many(frames).reshape(5, S, h, w)
+        for i in range(5):
+            for s in range(S):
+                assert np.array_equal(got[i, s], refs[s].apply(frames[i, s])), (r, i, s)
+    st = gpu.knn_state()
+    n = h * w
+    for s in range(S):
+        want = refs[s].export()
+        assert np.array_equal(st["samples"][:, :, s * n:(s + 1) * n], want["samples"])
+        assert np.array_equal(st["state"][:, s * n:(s + 1) * n], want["state"])
+
+
 def test_knn_pipeline_streams_and_1080p(oracle):
-    """KNN inside the pipeline (blur -> KNN -> erode -> dilate), two streams, several frames per
-    call; and one 1080p stream: masks equal the oracle pipeline, the model equals per stream."""
+    """... and with the box filter, and one 1080p stream."""
     from pygofpid_amd.foreground import ForegroundPipeline
     h, w, c, S = 60, 88, 3, 2
+    gb, rb = ForegroundPipeline((h, w, c), detector="KNN", blur=("box", 3, 3)), oracle.Pipeline(h, w, c, detector="KNN", blur_k=-3)
+    for t in range(6):
+        f = Clip(h, w, c, seed=4).frame(t)
+        assert np.array_equal(gb.apply(f), rb.apply(f)), t
     clips = [Clip(h, w, c, seed=20 + s, n_objects=2) for s in range(S)]
     gpu = ForegroundPipeline((h, w, c), streams=S, detector="KNN")
     refs = [oracle.Pipeline(h, w, c, detector="KNN") for _ in range(S)]
