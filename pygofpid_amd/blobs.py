@@ -100,8 +100,8 @@ class BlobExtractor:
 
 def contours_of(records, points):
     """The contours as cv2 returns them: a list of (n, 1, 2) int32 arrays."""
-    return [points[r["point_offset"]:r["point_offset"] + r["n_points"]].reshape(-1, 1, 2)
-            for r in records]
+    return [points[o:o + n].reshape(-1, 1, 2)
+            for o, n in zip(records["point_offset"].tolist(), records["n_points"].tolist())]
 
 
 def moments_of(rec):
@@ -120,17 +120,39 @@ def bottom_and_center(rec, dtype=np.int16):
             np.array([x, int(m["m01"] / m["m00"])], dtype=dtype))
 
 
+def _wrapped(rows, dtype):
+    # (int64 -> dtype as astype does it: modulo 2^bits, like the per-record np.array(..., dtype) for in-range values)
+    return np.array(rows, dtype=np.int64).reshape(-1, 2).astype(dtype)
+
+
 def bottoms_and_centers(records, dtype=np.int16):
     """bottom_and_center for all records at once: (n, 2) arrays of (x, y); the same float64
-    quotients truncated toward zero, element for element."""
+    quotients truncated toward zero, element for element.  (Python floats ARE float64 and
+    float(int) rounds as the C conversion does: with ~10 records per frame a loop over column
+    lists costs a fifth of the equivalent numpy expression's fixed overheads.)"""
     if len(records) == 0:
         z = np.zeros((0, 2), dtype)
         return z, z
+    bottoms, centers = [], []
+    for a00, a10, a01, ymax in zip(records["a00"].tolist(), records["a10"].tolist(),
+                                   records["a01"].tolist(), records["ymax"].tolist()):
+        if a00 == 0:
+            return _bottoms_and_centers_np(records, dtype)     # (inf / nan quotients: numpy's conversion rules)
+        s = -1.0 if a00 < 0 else 1.0
+        m00 = s * float(a00) / 2.0
+        x = int(s * float(a10) / 6.0 / m00)
+        bottoms.append((x, ymax))
+        centers.append((x, int(s * float(a01) / 6.0 / m00)))
+    return _wrapped(bottoms, dtype), _wrapped(centers, dtype)
+
+
+def _bottoms_and_centers_np(records, dtype):
     a00 = records["a00"].astype(np.float64)
     s = np.where(records["a00"] < 0, -1.0, 1.0)
-    m00, m10, m01 = s * a00 / 2.0, s * records["a10"].astype(np.float64) / 6.0, s * records["a01"].astype(np.float64) / 6.0
-    x = (m10 / m00).astype(np.int64)
-    cy = (m01 / m00).astype(np.int64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        m00, m10, m01 = s * a00 / 2.0, s * records["a10"].astype(np.float64) / 6.0, s * records["a01"].astype(np.float64) / 6.0
+        x = (m10 / m00).astype(np.int64)
+        cy = (m01 / m00).astype(np.int64)
     return (np.stack([x, records["ymax"].astype(np.int64)], 1).astype(dtype),
             np.stack([x, cy], 1).astype(dtype))
 

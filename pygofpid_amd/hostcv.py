@@ -106,20 +106,21 @@ def boundingRect(contour):
     return x0, y0, int(p[:, 0].max()) - x0 + 1, int(p[:, 1].max()) - y0 + 1
 
 
-def pointPolygonTest(contour, pt, measureDist=False):
-    """+1 inside, 0 on an edge, -1 outside (measureDist=False only; that is the
-    only form the reference uses, pipeline.py:739-743, helpers.py:63-74)."""
-    if measureDist:
-        raise NotImplementedError("measureDist=True is not used by the reference")
-    p = _xy(contour)
+def polygon_points(contour):
+    """The polygon's vertices as a list of [x, y] python floats (float64 values): what
+    point_in_polygon walks; python float arithmetic is the float64 arithmetic numpy would do,
+    without a numpy scalar per operation."""
+    return _xy(contour).tolist()
+
+
+def point_in_polygon(p, px, py):
+    """pointPolygonTest(., ., False) on polygon_points(): +1 inside, 0 on an edge, -1 outside."""
     n = len(p)
     if n == 0:
         return -1.0
-    px, py = float(pt[0]), float(pt[1])
     inside = False
-    for i in range(n):
-        x0, y0 = p[i - 1]
-        x1, y1 = p[i]
+    x0, y0 = p[-1]
+    for x1, y1 in p:
         # on the segment?
         cross = (x1 - x0) * (py - y0) - (y1 - y0) * (px - x0)
         if cross == 0 and min(x0, x1) <= px <= max(x0, x1) and min(y0, y1) <= py <= max(y0, y1):
@@ -128,7 +129,16 @@ def pointPolygonTest(contour, pt, measureDist=False):
             xi = x0 + (py - y0) * (x1 - x0) / (y1 - y0)
             if px < xi:
                 inside = not inside
+        x0, y0 = x1, y1
     return 1.0 if inside else -1.0
+
+
+def pointPolygonTest(contour, pt, measureDist=False):
+    """+1 inside, 0 on an edge, -1 outside (measureDist=False only; that is the
+    only form the reference uses, pipeline.py:739-743, helpers.py:63-74)."""
+    if measureDist:
+        raise NotImplementedError("measureDist=True is not used by the reference")
+    return point_in_polygon(polygon_points(contour), float(pt[0]), float(pt[1]))
 
 
 def norm(v):

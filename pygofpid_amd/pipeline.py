@@ -27,6 +27,8 @@ Deliberate deviations, all off the hot path:
     (NotImplementedError); 'KNN' keeps cv2's model and rule
     but draws its refresh slots from a hash instead of rand() (cv.BackgroundSubtractorKNN).
 """
+import math
+
 import numpy as np
 
 from . import blobs as gpublobs
@@ -42,6 +44,20 @@ _DEFAULT_POST_FILTER = {'perimeter': None, 'anchor': 'bottom', 'perspective': No
                         'perspective_coeff': 0.5, 'presence_min': 3, 'distance_min': 0.25}
 _DEFAULT_ALARM = {'keep_alarm': True, 'duration_min': 10}
 _UNSET = object()
+
+
+def _wrap(v, bits):
+    """A python int as the two's-complement integer of `bits` bits numpy would have kept."""
+    half = 1 << (bits - 1)
+    return ((v + half) & ((1 << bits) - 1)) - half
+
+
+def _argmin(row):
+    """np.argmin of a list of floats: the first smallest entry; the first NaN if there is one."""
+    for j, v in enumerate(row):
+        if v != v:
+            return j
+    return row.index(min(row))
 
 
 def _default_morph():
@@ -325,10 +341,13 @@ class GOFPID():
         slr = SimpleLinearRegression()
         self._perspective = {key: slr.fit(bottoms, val).predict_clip(rows, 0)
                              for key, val in samples.items()}
+        # (the same float64 values as python floats: steps 5-7 read a few per blob and frame)
+        self._perspective_rows = {key: np.asarray(val, dtype=np.float64).tolist()
+                                  for key, val in self._perspective.items()}
 
     def _predict_perspective(self, key, y):
-        y = min(max(int(y), 0), self.input_shape_[0] - 1)     # (np.clip of a scalar, without its overhead)
-        return self._perspective.get(key)[y]
+        rows = self._perspective_rows[key]
+        return rows[min(max(int(y), 0), len(rows) - 1)]       # (np.clip of a scalar, without its overhead)
 
     # ----------------------------------------------------------------- blobs
     def _find_blob(self, area_min=100):
@@ -336,13 +355,12 @@ class GOFPID():
             # contours, area filter and moments came from the device with the mask's header
             recs, pts = self._gpu_blobs
             bottoms, centers = gpublobs.bottoms_and_centers(recs, dtype=np.int16)   # all records at once
-            use_bottom = self.post_filter['anchor'] == 'bottom'
-            self.blobs_ = [{'contour': contour, 'anchor': bottoms[i] if use_bottom else centers[i],
-                            'bottom': bottoms[i], 'center': centers[i],
+            anchors = bottoms if self.post_filter['anchor'] == 'bottom' else centers
+            xmin, ymin, xmax, ymax = (recs[k].tolist() for k in ('xmin', 'ymin', 'xmax', 'ymax'))
+            self.blobs_ = [{'contour': contour, 'anchor': anchors[i], 'bottom': bottoms[i], 'center': centers[i],
                             # (cv.boundingRect of the contour, from the record's extremes)
-                            'bbox': (int(r['xmin']), int(r['ymin']), int(r['xmax'] - r['xmin'] + 1),
-                                     int(r['ymax'] - r['ymin'] + 1))}
-                           for i, (r, contour) in enumerate(zip(recs, gpublobs.contours_of(recs, pts)))]
+                            'bbox': (xmin[i], ymin[i], xmax[i] - xmin[i] + 1, ymax[i] - ymin[i] + 1)}
+                           for i, contour in enumerate(gpublobs.contours_of(recs, pts))]
             return
         contours = [c for c in find_contours(self.foreground_mask_)
                     if hostcv.contourArea(c) >= area_min]
@@ -365,19 +383,22 @@ class GOFPID():
                 self._update_unpaired_tracked_blob(j)
             return
 
-        dist = self._tracking_distances()
+        dist = self._tracking_distances().tolist() if self._slow_host_steps else self._tracking_distance_rows()
 
         for i in range(n_blobs):
-            j_min = np.argmin(dist[i])
-            if dist[i, j_min] <= 1:
-                dist[i, j_min] = -1          # mark the pair
+            row = dist[i]
+            j_min = _argmin(row)
+            if row[j_min] <= 1:
+                row[j_min] = -1              # mark the pair
                 self._update_paired_tracked_blob(j_min, i)
             else:
                 self.tracked_blobs_.append(self._create_tracked_blob(i))
 
         for j in reversed(range(n_tracked)):
-            if np.all(dist[:, j] >= 0):
+            if all(row[j] >= 0 for row in dist):
                 self._update_unpaired_tracked_blob(j)
+
+    _slow_host_steps = False     # True: the numpy forms below (the checkers of the python-scalar forms)
 
     def _tracking_distances(self):
         """_compute_tracking_distance for all (blob, tracked blob) pairs at once: the same int16 /
@@ -390,6 +411,62 @@ class GOFPID():
         ok = (r_maj > 0) & (r_min > 0)
         with np.errstate(divide='ignore', invalid='ignore', over='ignore'):
             return np.where(ok[None, :], delta[..., 0]**2 / r_maj**2 + delta[..., 1]**2 / r_min**2, 0.0)
+
+    def _tracking_distance_rows(self):
+        """_tracking_distances() as a list of rows of python floats, evaluated on python ints: the
+        int16 differences and squares and the int32 squared radii wrapped by hand, the float64
+        quotients by true division of exact integers (correctly rounded, as float64 / float64 of
+        exactly representable operands is).  With ~10 blobs this is several times cheaper than
+        the array form, whose cost is numpy's per-call overhead.  Anything the scalar form does
+        not cover (a squared radius wrapping to 0, non-finite or out-of-range gates, centres that
+        are not int16) goes through the array form."""
+        factor = self.tracking['factor']
+        heights = self._perspective_rows['height']
+        last = len(heights) - 1
+        try:
+            gates = []
+            for t in self.tracked_blobs_:
+                c = t['center']
+                if c.dtype != np.int16:
+                    raise ValueError
+                r_maj = heights[min(max(int(t['bottom'][1]), 0), last)] * factor
+                if not -2147483648.0 < r_maj < 2147483648.0:
+                    raise ValueError
+                r_maj = int(r_maj)                       # np.int32(float64): truncation
+                r_min = int(r_maj / 2)
+                cx, cy = c.tolist()
+                if r_maj > 0 and r_min > 0:
+                    r_maj, r_min = _wrap(r_maj * r_maj, 32), _wrap(r_min * r_min, 32)
+                    if r_maj == 0 or r_min == 0:
+                        raise ZeroDivisionError
+                    gates.append((cx, cy, r_maj, r_min))
+                else:
+                    gates.append((cx, cy, 0, 0))
+            rows = []
+            for b in self.blobs_:
+                c = b['center']
+                if c.dtype != np.int16:
+                    raise ValueError
+                bx, by = c.tolist()
+                row = []
+                for cx, cy, r_maj, r_min in gates:
+                    if r_maj:
+                        dx, dy = bx - cx, by - cy
+                        if not (-32768 <= dx <= 32767 and -32768 <= dy <= 32767):
+                            dx, dy = _wrap(dx, 16), _wrap(dy, 16)
+                        dx *= dx
+                        dy *= dy
+                        if dx > 32767:                   # (the int16 square wraps from |d| = 182 on)
+                            dx = ((dx + 32768) & 65535) - 32768
+                        if dy > 32767:
+                            dy = ((dy + 32768) & 65535) - 32768
+                        row.append(dx / r_maj + dy / r_min)
+                    else:
+                        row.append(0.0)
+                rows.append(row)
+            return rows
+        except (ValueError, ZeroDivisionError, OverflowError, AttributeError):
+            return self._tracking_distances().tolist()
 
     def _create_tracked_blob(self, i_blob):
         blob = self.blobs_[i_blob]
@@ -428,11 +505,18 @@ class GOFPID():
 
     def _compute_total_distance(self, i_tracked_blob):
         tracked = self.tracked_blobs_[i_tracked_blob]
-        dist = hostcv.norm(tracked['center'] - tracked['center_first'])
+        c, f = tracked['center'], tracked['center_first']
+        if self._slow_host_steps or c.dtype != np.int16 or f.dtype != np.int16:
+            dist = hostcv.norm(c - f)
+        else:
+            # the int16 difference (wrapping), its float64 norm: sqrt of an exact integer sum
+            (cx, cy), (fx, fy) = c.tolist(), f.tolist()
+            dx, dy = _wrap(cx - fx, 16), _wrap(cy - fy, 16)
+            dist = math.sqrt(float(dx * dx + dy * dy))
         area_min = self._predict_perspective('area', tracked['bottom'][1])
         if area_min <= 0:
             return 0
-        return dist / np.sqrt(area_min)
+        return dist / math.sqrt(area_min)
 
     def _update_unpaired_tracked_blob(self, i_tracked_blob):
         tracked = self.tracked_blobs_[i_tracked_blob]
@@ -444,20 +528,22 @@ class GOFPID():
 
     # ----------------------------------------------------------- post-filter
     def _post_filter(self):
+        perimeter = hostcv.polygon_points(self.post_filter['perimeter'])
+        coeff = self.post_filter['perspective_coeff']
         for tracked in self.tracked_blobs_:
-            inside = hostcv.pointPolygonTest(self.post_filter['perimeter'], tracked['anchor'],
-                                             False) >= 0
-            (tracked['filtered'].discard if inside else tracked['filtered'].add)('perimeter')
+            anchor, filtered = tracked['anchor'], tracked['filtered']
+            inside = hostcv.point_in_polygon(perimeter, float(anchor[0]), float(anchor[1])) >= 0
+            (filtered.discard if inside else filtered.add)('perimeter')
 
             _, _, width, height = tracked.get('bbox') or hostcv.boundingRect(tracked['contour'])
             area_persp = self._predict_perspective('area', tracked['bottom'][1])
-            big_enough = width * height > area_persp * self.post_filter['perspective_coeff']
-            (tracked['filtered'].discard if big_enough else tracked['filtered'].add)('perspective')
+            big_enough = width * height > area_persp * coeff
+            (filtered.discard if big_enough else filtered.add)('perspective')
 
     def _detect_blob(self):
         blob_in_alarm = False
         for tracked in self.tracked_blobs_:
-            if tracked['filtered'] == set():
+            if not tracked['filtered']:
                 blob_in_alarm = True
                 if self.alarm_def['keep_alarm']:
                     tracked['already_in_alarm'] = True

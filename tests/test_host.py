@@ -244,8 +244,67 @@ def test_tracking_distances_all_pairs_equal_the_scalar_rule():
         warnings.simplefilter("ignore")
         want = np.array([[g._compute_tracking_distance(j, i) for j in range(7)] for i in range(9)], dtype=np.float64)
         got = g._tracking_distances()
+        rows = g._tracking_distance_rows()
     assert got.shape == (9, 7) and got.dtype == np.float64
     assert np.array_equal(got, want)
+    # ... and the python-int form _track_blob reads (wrapping done by hand)
+    assert all(type(v) is float for r in rows for v in r) and np.array_equal(np.array(rows), want)
+    # what the python-int form does not cover goes through the array form: a radius whose square wraps to 0
+    g.tracking['factor'] = 65536.0 / g._predict_perspective('height', 300)
+    g.tracked_blobs_[0]['bottom'] = np.array([0, 300], np.int16)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        assert np.array_equal(np.array(g._tracking_distance_rows()), g._tracking_distances(), equal_nan=True)
+
+
+def _rect_record(x, y, w, h, off):
+    xs, ys = list(range(x, x + w)), list(range(y, y + h))
+    p = np.array([(xx, y) for xx in xs] + [(x + w - 1, yy) for yy in ys[1:]] + [(xx, y + h - 1) for xx in xs[-2::-1]]
+                 + [(x, yy) for yy in ys[-2:0:-1]], np.int64)
+    x0, y0 = np.roll(p[:, 0], 1), np.roll(p[:, 1], 1)
+    cr = x0 * p[:, 1] - p[:, 0] * y0
+    return (p[0, 0], p[0, 1], p[:, 0].min(), p[:, 1].min(), p[:, 0].max(), p[:, 1].max(), len(p), off,
+            cr.sum(), (cr * (x0 + p[:, 0])).sum(), (cr * (y0 + p[:, 1])).sum()), p.astype(np.int32)
+
+
+def test_host_steps_python_scalar_forms_equal_the_numpy_forms():
+    """Steps 5-7 (tracking, post-filter, alarm) on python ints / floats vs the numpy forms they
+    restate (`_slow_host_steps`): the same tracked blobs, flags and alarms, frame after frame, on
+    device-style blob records of objects that appear, cross, leave the perimeter and vanish."""
+    from pygofpid_amd import blobs as gb
+    from pygofpid_amd.pipeline import GOFPID
+    rng = np.random.default_rng(5)
+    objs = [(int(rng.integers(0, 560)), int(rng.integers(0, 380)), int(rng.integers(-4, 5)), int(rng.integers(-2, 3)),
+             int(rng.integers(12, 60)), int(rng.integers(12, 90)), int(rng.integers(0, 60)), int(rng.integers(80, 300)))
+            for _ in range(14)]
+    frames = []
+    for t in range(300):
+        recs, pts, off = [], [], 0
+        for (x0, y0, vx, vy, w, h, t0, t1) in objs:
+            x, y = x0 + vx * t, y0 + vy * t
+            if t0 <= t < t1 and t % 11 != 3 and 0 <= x and x + w <= 640 and 0 <= y and y + h <= 480:
+                r, p = _rect_record(x, y, w, h, off)
+                recs.append(r), pts.append(p)
+                off += len(p)
+        frames.append((np.array(recs, gb.RECORD_DTYPE) if recs else np.zeros(0, gb.RECORD_DTYPE),
+                       np.concatenate(pts) if pts else np.zeros((0, 2), np.int32)))
+    runs = []
+    for slow in (True, False):
+        g = GOFPID(alarm_def={'keep_alarm': True, 'duration_min': 5}).initialize()
+        g._slow_host_steps = slow
+        g.input_shape_ = (480, 640, 3)
+        g._calib_first_frame()
+        log = []
+        for res in frames:
+            g._gpu_blobs = res
+            g._find_blob(), g._track_blob(), g._post_filter()
+            alarm = g._maintain_alarm(g._detect_blob())
+            log.append((alarm, [(t['center'].tolist(), t['bottom'].tolist(), t['anchor'].tolist(), t['center_first'].tolist(),
+                                 t['presence'], t['absence'], sorted(t['filtered']), t['already_in_alarm'], t['bbox'])
+                                for t in g.tracked_blobs_]))
+        runs.append(log)
+    assert runs[0] == runs[1]
+    assert any(a for a, _ in runs[0]) and not all(a for a, _ in runs[0]) and max(len(t) for _, t in runs[0]) >= 5
 
 
 def test_bottoms_and_centers_vectorised_equals_per_record():
