@@ -25,6 +25,8 @@ def child(kind, T):
     ctx = _lib.Context(0)
     if kind == "convert":
         pipe = ForegroundPipeline((h, w, 3), streams=S, ctx=ctx, convert="BGR2GRAY")
+    elif kind in ("fd_convert", "knn_convert"):
+        pipe = ForegroundPipeline((h, w, 3), streams=S, ctx=ctx, convert="BGR2GRAY", detector=kind[:-8].upper())
     else:
         pipe = ForegroundPipeline((h, w, 3), streams=S, ctx=ctx, blur=("box", 3, 3))
     i = 0
@@ -42,11 +44,13 @@ def child(kind, T):
         step()
     pipe.synchronize()
     dt = (time.perf_counter() - t0) / n
-    print(json.dumps({"us_per_step": dt * 1e6, "frames_per_s": S * T / dt, "mbar": pipe.mean_modes()}))
+    print(json.dumps({"us_per_step": dt * 1e6, "frames_per_s": S * T / dt,
+                      "mbar": pipe.mean_modes() if pipe.detector == "MOG2" else 0.0}))
 
 
 def main():
-    for kind, knob in (("convert", "GOF_NO_FUSE_STEP0"), ("box", "GOF_NO_FUSE_BOX")):
+    for kind, knob in (("convert", "GOF_NO_FUSE_STEP0"), ("box", "GOF_NO_FUSE_BOX"),
+                       ("fd_convert", "GOF_NO_FUSE_STEP0"), ("knn_convert", "GOF_NO_FUSE_STEP0")):
         for T in (8, 1):
             row = []
             for fused in (True, False):
@@ -56,8 +60,10 @@ def main():
                 out = subprocess.run([sys.executable, os.path.abspath(__file__)], env=env, capture_output=True, text=True)
                 line = [l for l in out.stdout.splitlines() if l.startswith("{")]
                 row.append(json.loads(line[-1]) if line else {"us_per_step": float("nan"), "frames_per_s": 0, "mbar": 0})
-            what = ("BGR -> grey (step 0) + GaussianBlur 3x3 + MOG2 (grey model) + 5x5 erode / dilate" if kind == "convert"
-                    else "cv.blur 3x3 + MOG2 (BGR model) + 5x5 erode / dilate")
+            what = {"convert": "BGR -> grey (step 0) + GaussianBlur 3x3 + MOG2 (grey model) + 5x5 erode / dilate",
+                    "box": "cv.blur 3x3 + MOG2 (BGR model) + 5x5 erode / dilate",
+                    "fd_convert": "BGR -> grey (step 0) + GaussianBlur 3x3 + frame differencing + 5x5 erode / dilate",
+                    "knn_convert": "BGR -> grey (step 0) + GaussianBlur 3x3 + KNN (grey model) + 5x5 erode / dilate"}[kind]
             print("%s, 8 x 1080p, %d frame(s) per step:\n    fused %8.1f us per step (%7.0f frames/s)   own kernel %8.1f us per step (%7.0f frames/s)   m-bar %.2f"
                   % (what, T, row[0]["us_per_step"], row[0]["frames_per_s"], row[1]["us_per_step"], row[1]["frames_per_s"], row[0]["mbar"]))
 

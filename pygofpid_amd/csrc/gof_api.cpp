@@ -1507,11 +1507,24 @@ int gof_pipeline_apply_dev_many(gof_pipeline *p, const void *d_frames, void *d_m
     // detector launch); otherwise its own kernel
     bool cvt_fused = false;
     static const bool no_step0_fusion = getenv("GOF_NO_FUSE_STEP0") != nullptr;   // A/B knob (profiles/)
-    if (p->cvt_c && p->mog2 && p->fuse_blur3 && d.c == 1 && !no_step0_fusion) {
-        gofk::Mog2Consts kc{};
-        kc.var_min = p->mog2->p.var_min;
-        kc.var_max = p->mog2->p.var_max;
-        cvt_fused = gofk::mog2_convert_supported(x, d.streams, d.h, d.w, p->cvt_c, p->taps, kc);
+    static const bool no_knn_fusion = getenv("GOF_NO_FUSE_KNN_BLUR") != nullptr;  // A/B knob (profiles/)
+    if (p->cvt_c && d.c == 1 && !no_step0_fusion) {
+        if (p->mog2 && p->fuse_blur3) {
+            gofk::Mog2Consts kc{};
+            kc.var_min = p->mog2->p.var_min;
+            kc.var_max = p->mog2->p.var_max;
+            cvt_fused = gofk::mog2_convert_supported(x, d.streams, d.h, d.w, p->cvt_c, p->taps, kc);
+        } else if (p->fd && p->fuse_fd3 && p->fd_mode != 2 && T > 1) {
+            // multi-frame calls only: one-frame calls are faster through gray_quad_kernel (the staged
+            // conversion works on 1.5 x the pixels, with a second barrier; profiles/r03_step0_box_fusion.txt),
+            // and so is KNN, one launch per frame.  (The grey frames must suit the fused kernel as well:
+            // a call whose colour frames do not -- a misaligned pointer -- goes through the grey buffer
+            // and then the same kernel; the hand-over format between launches is the same.)
+            cvt_fused = gofk::fd_frames_supported(x, d.streams, d.h, d.w, 1, p->taps, p->cvt_c) &&
+                        gofk::fd_frames_supported(nullptr, d.streams, d.h, d.w, 1, p->taps);
+            if (cvt_fused)
+                p->fd_mode = 1;
+        }
     }
     if (p->cvt_c && !cvt_fused) {
         if ((rc = p->gray.reserve((size_t)T * npx)))
@@ -1519,6 +1532,7 @@ int gof_pipeline_apply_dev_many(gof_pipeline *p, const void *d_frames, void *d_m
         GOF_HIP(gofk::cvt_gray(x, (uint8_t *)p->gray.p, T * d.streams, d.h, d.w, p->cvt_c, p->cvt_rgb, s));
         x = (const uint8_t *)p->gray.p;
     }
+    const int xc = cvt_fused ? p->cvt_c : d.c;   // channels of the frames at x
     // step 1 (pipeline.py:462-467) -- unless it is fused into step 2
     // FD: the fused kernel needs aligned frames.  The choice is made on the first
     // call and kept (the two paths keep the previous frame in different formats); a
@@ -1526,14 +1540,13 @@ int gof_pipeline_apply_dev_many(gof_pipeline *p, const void *d_frames, void *d_m
     if (p->fuse_fd3 && p->fd && p->fd_mode == 0)
         p->fd_mode = gofk::fd_frames_supported(x, d.streams, d.h, d.w, d.c, p->taps) ? 1 : 2;
     const bool fd_fused = p->fd_mode == 1;
-    if (fd_fused && !gofk::fd_frames_supported(x, d.streams, d.h, d.w, d.c, p->taps)) {
+    if (fd_fused && !cvt_fused && !gofk::fd_frames_supported(x, d.streams, d.h, d.w, d.c, p->taps)) {
         if ((rc = p->in.reserve((size_t)T * npx * d.c)))
             return rc;
         GOF_HIP(hipMemcpyAsync(p->in.p, x, (size_t)T * npx * d.c, hipMemcpyDeviceToDevice, s));
         x = (const uint8_t *)p->in.p;
     }
     // KNN: the 3x3 blur runs inside the KNN kernel when the frames are aligned (as the fused FD kernel)
-    static const bool no_knn_fusion = getenv("GOF_NO_FUSE_KNN_BLUR") != nullptr;   // A/B knob (profiles/)
     const bool knn_fused = p->knn && d.blur != GOF_BLUR_NONE && p->taps.fused3_ok && !no_knn_fusion &&
                            gofk::knn_blur3_supported(x, d.streams, d.h, d.w, d.c, p->taps);
     if (d.blur != GOF_BLUR_NONE && !p->fuse_blur3 && !fd_fused && !knn_fused) {
@@ -1604,7 +1617,7 @@ int gof_pipeline_apply_dev_many(gof_pipeline *p, const void *d_frames, void *d_m
     } else if (fd_fused) {
         // blur + difference for up to kMaxT frames per launch; the blurred last frame is
         // handed from launch to launch in fd_prev
-        const size_t bytes = npx * d.c;
+        const size_t bytes = npx * xc;
         if ((rc = p->fd_prev[0].reserve(npx * 4)) || (rc = p->fd_prev[1].reserve(npx * 4)))
             return rc;
         const size_t rf_chunk = (size_t)d.streams * d.h * gofk::rowflag_pitch(d.w);
@@ -1620,7 +1633,8 @@ int gof_pipeline_apply_dev_many(gof_pipeline *p, const void *d_frames, void *d_m
                                           (uint32_t *)p->fd_prev[p->fd_cur].p, p->fd_has_prev,
                                           fd_ithr(p->fd->threshold), d.streams, d.h, d.w, d.c, tn,
                                           p->taps, s,
-                                          rf ? rf + (size_t)(t0 / gofk::kMaxT) * rf_chunk : nullptr));
+                                          rf ? rf + (size_t)(t0 / gofk::kMaxT) * rf_chunk : nullptr,
+                                          cvt_fused ? p->cvt_c : 0, p->cvt_rgb));
             p->fd_cur ^= 1;
             p->fd_has_prev = true;
         }
@@ -1919,7 +1933,8 @@ int gof_pipeline_algorithmic_bytes(gof_pipeline *p, double mean_modes, int n_fra
     // detector: every frame in and every mask out; the MOG2 model moves once per
     // launch of up to kMaxT frames (temporal blocking), FD state once per frame
     // (a converting pipeline whose 3x3 blur is fused reads the colour frames in the detector kernel)
-    const bool cvt_fused = p->cvt_c && p->mog2 && p->fuse_blur3 && d.c == 1;
+    const bool cvt_fused = p->cvt_c && d.c == 1 &&
+                           ((p->mog2 && p->fuse_blur3) || (p->fd && p->fd_mode == 1 && n_frames > 1));
     double det = T * ((cvt_fused ? p->cvt_c : d.c) + 1.0);
     if (p->mog2) {
         const double launches = (double)((n_frames + gofk::kMaxT - 1) / gofk::kMaxT);
@@ -1930,7 +1945,7 @@ int gof_pipeline_algorithmic_bytes(gof_pipeline *p, double mean_modes, int n_fra
     double tot = det;
     if (p->cvt_c && !cvt_fused)
         tot += T * (p->cvt_c + 1.0);                           // step 0 as its own kernel
-    if (d.blur != GOF_BLUR_NONE && !p->fuse_blur3 && !(p->knn && p->taps.fused3_ok))
+    if (d.blur != GOF_BLUR_NONE && !p->fuse_blur3 && !(p->fd && p->fd_mode == 1) && !(p->knn && p->taps.fused3_ok))
         tot += T * 2.0 * d.c;                                  // blurred image written + read
     const int morph_kernels = d.n_morph == 0 ? 0 : (p->chain_ok ? 1 : d.n_morph);
     tot += T * 2.0 * morph_kernels;                            // each reads a mask, writes a mask

@@ -137,10 +137,13 @@ hipError_t fd_apply(const uint8_t *cur, const uint8_t *prev, bool has_prev, int 
 // to launch through prev_in / prev_out (one dword per pixel, n_img*h*w of them each,
 // distinct buffers; the kernels' own format).
 // fd_frames_supported: 3x3 byte taps, aligned rows / frames (as the fused MOG2 path).
-bool fd_frames_supported(const uint8_t *frame, int n_img, int h, int w, int c, const Taps &t);
+// src_c != 0: step 0 inside the kernel -- the frames arrive with src_c (3 | 4) channels, BGR(A) or
+// RGB(A) order, and are converted to grey (c == 1) on the staged tiles.
+bool fd_frames_supported(const uint8_t *frame, int n_img, int h, int w, int c, const Taps &t, int src_c = 0);
 hipError_t fd_frames_apply(const uint8_t *frame, uint8_t *mask, const uint32_t *prev_in,
                            uint32_t *prev_out, bool has_prev, int ithr, int n_img, int h, int w, int c,
-                           int T, const Taps &t, hipStream_t s, uint8_t *rowflags = nullptr);
+                           int T, const Taps &t, hipStream_t s, uint8_t *rowflags = nullptr, int src_c = 0,
+                           bool src_rgb = false);
 
 hipError_t morph_generic(int op, const uint8_t *src, uint8_t *dst, int n_img, int h, int w,
                          const SeBits &se, hipStream_t s);

@@ -56,14 +56,20 @@ struct FdFramesArgs {
     size_t frame_stride, mask_stride;
     int H, W, T, has_prev, ithr, flag_pitch;
     uint32_t kxw, vky0, vky1, vround;   // (as Mog2FramesArgs)
+    int g0, g1, g2;                     // CS != 0: luma weights of source channels 0 / 1 / 2
 };
 
-template <int C, int NT>   // NT: frames staged per launch (1 for the per-frame call, else kMaxT)
+// NT: frames staged per launch (1 for the per-frame call, else kMaxT).  CS: channels of the frames as
+// they arrive when step 0 (cv.cvtColor to grey) is switched on -- the colour rows are staged and the
+// grey tile is built in LDS (gray_tiles_from_staged), as in mog2_frames_kernel; C == 1 then.
+template <int C, int NT, int CS = 0>
 __global__ __launch_bounds__(256) void fd_frames_kernel(const FdFramesArgs a)
 {
-    typedef FrameTiles<C, NT> Tiles;
-    constexpr int ROWD = Tiles::ROWD, TILE = Tiles::TILE;
-    __shared__ uint32_t tiles[Tiles::LDS_DWORDS];
+    static_assert(CS == 0 || C == 1, "the conversion produces one channel");
+    typedef FrameTiles<(CS ? CS : C), NT> Tiles;
+    constexpr int ROWD = CS ? kGrayRowD : Tiles::ROWD, TILE = (TH + 2) * ROWD;
+    __shared__ uint32_t tiles[NT * TILE];
+    __shared__ uint32_t ctiles[CS ? Tiles::LDS_DWORDS : 1];   // the raw colour tiles (CS != 0)
 
     const int H = a.H, W = a.W, T = a.T;
     const int lane = threadIdx.x & 63;
@@ -87,14 +93,19 @@ __global__ __launch_bounds__(256) void fd_frames_kernel(const FdFramesArgs a)
     for (int c = 0; c < C; c++)
         prev[c] = (prev_px >> (8 * c)) & 255u;
 
-    Tiles::store(tiles, wave, lane, raw);
+    Tiles::store(CS ? ctiles : tiles, wave, lane, raw);
     TapPatterns<C> taps;
-    taps.build(valid ? x : x0, W, ft.sx0, ft.mis0, a.kxw);
+    // (a grey tile row starts with the pixel itself: no offset within its first dword)
+    taps.build(valid ? x : x0, W, ft.sx0, CS ? 0 : ft.mis0, a.kxw);
     uint32_t wa = (uint32_t)(wave * ROWD) * 4u + (uint32_t)taps.A;
     uint32_t half = a.vround;
     asm volatile("" : "+v"(half));
     const uint32_t ky[3] = {a.vky0, a.vky1, a.vky0};
     __syncthreads();
+    if constexpr (CS != 0) {
+        gray_tiles_from_staged<CS, NT>(ctiles, tiles, ft, x0, W, wave, lane, a.g0, a.g1, a.g2);
+        __syncthreads();
+    }
 
     uint8_t *mp = a.mask + pix;
     bool have = a.has_prev != 0;   // the first frame ever gives an all-zero mask
@@ -852,6 +863,23 @@ __global__ __launch_bounds__(256) void gray_kernel(const uint8_t *__restrict__ s
     dst[i] = (uint8_t)((p[0] * c0 + p[1] * c1 + p[2] * c2 + (1 << 13)) >> 14);
 }
 
+// four pixels per thread: CS aligned dwords in, one dword out (GrayQuad: the same integers)
+template <int CS>
+__global__ __launch_bounds__(256) void gray_quad_kernel(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst,
+                                                        size_t nquads, int g0, int g1, int g2)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nquads)
+        return;
+    GrayQuad<CS> gq;
+    gq.build(g0, g1, g2);
+    uint32_t d[CS];
+#pragma unroll
+    for (int q = 0; q < CS; q++)
+        d[q] = src[i * CS + q];
+    dst[i] = gq.convert(d);
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------
@@ -896,21 +924,25 @@ hipError_t fd_apply(const uint8_t *cur, const uint8_t *prev, bool has_prev, int 
     return hipGetLastError();
 }
 
-bool fd_frames_supported(const uint8_t *frame, int n_img, int h, int w, int c, const Taps &t)
+bool fd_frames_supported(const uint8_t *frame, int n_img, int h, int w, int c, const Taps &t, int src_c)
 {
     // byte taps whose folded outer pair fits a byte, at least two columns, and every
-    // staged row of every frame at the same offset mod 4 (see mog2_apply)
-    return t.fused3_ok && t.vky[0] == t.vky[2] && t.kx[0] + t.kx[2] <= 255 && w > 1 && ((size_t)w * c) % 4 == 0 &&
-           ((size_t)h * w * c) % 4 == 0 && ((size_t)n_img * h * w * c) % 4 == 0 &&
+    // staged row of every frame at the same offset mod 4 (see mog2_apply).  src_c != 0: the
+    // frames arrive with src_c (3 | 4) channels and are converted to grey (c == 1) on the staged tiles
+    if (src_c != 0 && (c != 1 || (src_c != 3 && src_c != 4)))
+        return false;
+    const int cc = src_c ? src_c : c;
+    return t.fused3_ok && t.vky[0] == t.vky[2] && t.kx[0] + t.kx[2] <= 255 && w > 1 && ((size_t)w * cc) % 4 == 0 &&
+           ((size_t)h * w * cc) % 4 == 0 && ((size_t)n_img * h * w * cc) % 4 == 0 &&
            (uintptr_t)frame % 4 == 0 && (c == 1 || c == 3 || c == 4);
 }
 
 hipError_t fd_frames_apply(const uint8_t *frame, uint8_t *mask, const uint32_t *prev_in,
                            uint32_t *prev_out, bool has_prev, int ithr, int n_img, int h, int w, int c,
-                           int T, const Taps &t, hipStream_t s, uint8_t *rowflags)
+                           int T, const Taps &t, hipStream_t s, uint8_t *rowflags, int src_c, bool src_rgb)
 {
     if (n_img < 1 || h < 1 || (h + TH - 1) / TH > 65535 || n_img > 65535 || T < 1 || T > kMaxT ||
-        !fd_frames_supported(frame, n_img, h, w, c, t) || !prev_out || (has_prev && !prev_in))
+        !fd_frames_supported(frame, n_img, h, w, c, t, src_c) || !prev_out || (has_prev && !prev_in))
         return hipErrorInvalidValue;
     FdFramesArgs a;
     a.frame = frame;
@@ -918,13 +950,14 @@ hipError_t fd_frames_apply(const uint8_t *frame, uint8_t *mask, const uint32_t *
     a.prev_in = prev_in;
     a.prev_out = prev_out;
     a.rowflags = rowflags;
-    a.frame_stride = (size_t)n_img * h * w * c;
+    a.frame_stride = (size_t)n_img * h * w * (src_c ? src_c : c);
     a.mask_stride = (size_t)n_img * h * w;
     a.H = h;
     a.W = w;
     a.T = T;
     a.has_prev = has_prev ? 1 : 0;
     a.ithr = ithr;
+    gray_weights(src_rgb, a.g0, a.g1, a.g2);
     a.flag_pitch = rowflag_pitch(w);
     a.kxw = (uint32_t)t.kx[0] | ((uint32_t)t.kx[1] << 8) | ((uint32_t)t.kx[2] << 16);
     a.vky0 = t.vky[0];
@@ -938,6 +971,17 @@ hipError_t fd_frames_apply(const uint8_t *frame, uint8_t *mask, const uint32_t *
         else                                                                                \
             hipLaunchKernelGGL((fd_frames_kernel<CC, kMaxT>), g, dim3(256), 0, s, a);       \
     } while (0)
+    if (src_c) {
+        if (T == 1 && src_c == 3)
+            hipLaunchKernelGGL((fd_frames_kernel<1, 1, 3>), g, dim3(256), 0, s, a);
+        else if (T == 1)
+            hipLaunchKernelGGL((fd_frames_kernel<1, 1, 4>), g, dim3(256), 0, s, a);
+        else if (src_c == 3)
+            hipLaunchKernelGGL((fd_frames_kernel<1, kMaxT, 3>), g, dim3(256), 0, s, a);
+        else
+            hipLaunchKernelGGL((fd_frames_kernel<1, kMaxT, 4>), g, dim3(256), 0, s, a);
+        return hipGetLastError();
+    }
     switch (c) {
     case 1: GOF_LAUNCH_FD(1); break;
     case 3: GOF_LAUNCH_FD(3); break;
@@ -1061,12 +1105,24 @@ hipError_t cvt_gray(const uint8_t *src, uint8_t *dst, int n_img, int h, int w, i
     if (n_img < 1 || h < 1 || w < 1 || (c != 3 && c != 4))
         return hipErrorInvalidValue;
     size_t npix = (size_t)n_img * h * w;
-    size_t blocks = (npix + 255) / 256;
-    if (blocks > 0x7fffffffu)
+    if ((npix + 255) / 256 > 0x7fffffffu)
         return hipErrorInvalidValue;
-    const int B2Y = 1868, G2Y = 9617, R2Y = 4899;
-    hipLaunchKernelGGL(gray_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, dst, npix, c,
-                       rgb ? R2Y : B2Y, G2Y, rgb ? B2Y : R2Y);
+    int g0, g1, g2;
+    gray_weights(rgb, g0, g1, g2);
+    // aligned buffers: four pixels per thread on dwords; the last npix % 4 pixels (and everything else) bytewise
+    size_t done = 0;
+    if ((uintptr_t)src % 4 == 0 && (uintptr_t)dst % 4 == 0 && npix >= 4) {
+        const size_t nquads = npix / 4;
+        const dim3 gq((unsigned)((nquads + 255) / 256));
+        if (c == 3)
+            hipLaunchKernelGGL(gray_quad_kernel<3>, gq, dim3(256), 0, s, (const uint32_t *)src, (uint32_t *)dst, nquads, g0, g1, g2);
+        else
+            hipLaunchKernelGGL(gray_quad_kernel<4>, gq, dim3(256), 0, s, (const uint32_t *)src, (uint32_t *)dst, nquads, g0, g1, g2);
+        done = nquads * 4;
+    }
+    if (done < npix)
+        hipLaunchKernelGGL(gray_kernel, dim3((unsigned)((npix - done + 255) / 256)), dim3(256), 0, s, src + done * c,
+                           dst + done, npix - done, c, g0, g1, g2);
     return hipGetLastError();
 }
 

@@ -783,6 +783,120 @@ struct FrameTiles {
     }
 };
 
+// Step 0 (cv.cvtColor to grey, pipeline.py:458-459) on staged tiles: the frames arrive with CS (3 | 4)
+// channels, FrameTiles<CS, NT> stages their rows as it stages any frame, and this turns every staged
+// pixel of every staged row of every frame -- (B * g0 + G * g1 + R * g2 + 2^13) >> 14, gray_kernel's
+// statement -- into a grey tile of kGrayRowD dwords per row (pixel sx0 at byte 0), on which the blur
+// runs with a zero start offset: no grey image ever exists in HBM.  Between two workgroup barriers
+// (the colour tiles complete before, the grey tiles complete after).
+constexpr int kGrayRowD = 20;   // dwords per grey tile row: 66 px + the 12-byte window's reach
+
+// Four pixels at a time: their 12 (CS = 3) or 16 (CS = 4) bytes as aligned dwords, the 14-bit weights
+// split into low and high bytes, one v_dot4_u32_u8 per (dword, pixel, half) that holds channel bytes of
+// the pixel -- grey = (lo + 256 hi + 2^13) >> 14 is the statement above with the products regrouped
+// (exact integers either way); the four grey bytes leave as one dword.
+template <int CS>
+struct GrayQuad {
+    uint32_t lo[CS == 3 ? 6 : 1], hi[CS == 3 ? 6 : 1];   // byte patterns (wave-uniform)
+
+    __device__ __forceinline__ static uint32_t pat(uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+    {
+        return a | (b << 8) | (c << 16) | (d << 24);
+    }
+    __device__ __forceinline__ void build(int g0, int g1, int g2)
+    {
+        const uint32_t w[3] = {(uint32_t)g0, (uint32_t)g1, (uint32_t)g2};
+        uint32_t l[3], h[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            l[k] = w[k] & 255u;
+            h[k] = w[k] >> 8;
+        }
+        if (CS == 3) {
+            // bytes of the quad: c0 c1 c2 c0 | c1 c2 c0 c1 | c2 c0 c1 c2
+            lo[0] = pat(l[0], l[1], l[2], 0), hi[0] = pat(h[0], h[1], h[2], 0);   // pixel 0 in dword 0
+            lo[1] = pat(0, 0, 0, l[0]), hi[1] = pat(0, 0, 0, h[0]);               // pixel 1 in dword 0
+            lo[2] = pat(l[1], l[2], 0, 0), hi[2] = pat(h[1], h[2], 0, 0);         // pixel 1 in dword 1
+            lo[3] = pat(0, 0, l[0], l[1]), hi[3] = pat(0, 0, h[0], h[1]);         // pixel 2 in dword 1
+            lo[4] = pat(l[2], 0, 0, 0), hi[4] = pat(h[2], 0, 0, 0);               // pixel 2 in dword 2
+            lo[5] = pat(0, l[0], l[1], l[2]), hi[5] = pat(0, h[0], h[1], h[2]);   // pixel 3 in dword 2
+        } else {
+            lo[0] = pat(l[0], l[1], l[2], 0), hi[0] = pat(h[0], h[1], h[2], 0);
+        }
+    }
+    __device__ __forceinline__ static uint32_t finish(uint32_t l0, uint32_t h0, uint32_t l1, uint32_t h1, uint32_t l2,
+                                                      uint32_t h2, uint32_t l3, uint32_t h3)
+    {
+        // (the low sums start from 2^13)
+        const uint32_t y0 = (l0 + (h0 << 8)) >> 14, y1 = (l1 + (h1 << 8)) >> 14;
+        const uint32_t y2 = (l2 + (h2 << 8)) >> 14, y3 = (l3 + (h3 << 8)) >> 14;
+        return y0 | (y1 << 8) | (y2 << 16) | (y3 << 24);
+    }
+    // d[0 .. CS): the quad's dwords
+    __device__ __forceinline__ uint32_t convert(const uint32_t (&d)[CS]) const
+    {
+        constexpr uint32_t R = 1u << 13;
+        if constexpr (CS == 3) {
+            const uint32_t l0 = __builtin_amdgcn_udot4(d[0], lo[0], R, false), h0 = __builtin_amdgcn_udot4(d[0], hi[0], 0u, false);
+            uint32_t l1 = __builtin_amdgcn_udot4(d[0], lo[1], R, false), h1 = __builtin_amdgcn_udot4(d[0], hi[1], 0u, false);
+            l1 = __builtin_amdgcn_udot4(d[1], lo[2], l1, false), h1 = __builtin_amdgcn_udot4(d[1], hi[2], h1, false);
+            uint32_t l2 = __builtin_amdgcn_udot4(d[1], lo[3], R, false), h2 = __builtin_amdgcn_udot4(d[1], hi[3], 0u, false);
+            l2 = __builtin_amdgcn_udot4(d[2], lo[4], l2, false), h2 = __builtin_amdgcn_udot4(d[2], hi[4], h2, false);
+            const uint32_t l3 = __builtin_amdgcn_udot4(d[2], lo[5], R, false), h3 = __builtin_amdgcn_udot4(d[2], hi[5], 0u, false);
+            return finish(l0, h0, l1, h1, l2, h2, l3, h3);
+        } else {
+            uint32_t l[4], h[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                l[k] = __builtin_amdgcn_udot4(d[k], lo[0], R, false);
+                h[k] = __builtin_amdgcn_udot4(d[k], hi[0], 0u, false);
+            }
+            return finish(l[0], h[0], l[1], h[1], l[2], h[2], l[3], h[3]);
+        }
+    }
+};
+
+template <int CS, int NT>
+__device__ __forceinline__ void gray_tiles_from_staged(const uint32_t *ctiles, uint32_t *tiles,
+                                                       const FrameTiles<CS, NT> &ft, int /*x0*/, int /*W*/, int /*wave*/,
+                                                       int /*lane*/, int g0, int g1, int g2)
+{
+    // a task = four consecutive staged pixels of one staged row of one frame: CS aligned dwords in
+    // (one more and a byte shift when the row's first pixel does not start its dword), one dword out.
+    // 17 quads cover a row's <= 66 staged pixels (what lies beyond them is never read back); the
+    // colour row's pitch covers the reads (CS = 3: dwords < 3 * 17 + 1 <= 64).
+    constexpr int QUADS = (TW + 2 + 3) / 4, CROWD = FrameTiles<CS, NT>::ROWD, NTASK = NT * (TH + 2) * QUADS;
+    static_assert(QUADS * CS + 1 <= CROWD && QUADS <= kGrayRowD, "quads stay inside the tile rows");
+    GrayQuad<CS> gq;
+    gq.build(g0, g1, g2);
+    const uint32_t sh = (uint32_t)ft.mis0;   // bytes (0 for CS = 4: a pixel is a dword)
+    for (int id = (int)threadIdx.x; id < NTASK; id += 256) {
+        const int row = id / QUADS, k = id - row * QUADS;
+        const uint32_t *c = ctiles + (size_t)row * CROWD + k * CS;
+        uint32_t d[CS];
+        if constexpr (CS == 3) {
+            const uint32_t r0 = c[0], r1 = c[1], r2 = c[2], r3 = c[3];
+            d[0] = __builtin_amdgcn_alignbyte(r1, r0, sh);
+            d[1] = __builtin_amdgcn_alignbyte(r2, r1, sh);
+            d[2] = __builtin_amdgcn_alignbyte(r3, r2, sh);
+        } else {
+#pragma unroll
+            for (int q = 0; q < CS; q++)
+                d[q] = c[q];
+        }
+        tiles[(size_t)row * kGrayRowD + k] = gq.convert(d);
+    }
+}
+
+// the luma weights of source channels 0 / 1 / 2 (cvt_gray's, 14-bit)
+inline void gray_weights(bool src_rgb, int &g0, int &g1, int &g2)
+{
+    const int B2Y = 1868, G2Y = 9617, R2Y = 4899;
+    g0 = src_rgb ? R2Y : B2Y;
+    g1 = G2Y;
+    g2 = src_rgb ? B2Y : R2Y;
+}
+
 // Lane-invariant blur addressing.  The three pixels a lane needs from a staged row
 // (left, centre, right; the border reflection can fold left onto right) lie within
 // 12 bytes of the aligned address A below the leftmost of them.  Instead of

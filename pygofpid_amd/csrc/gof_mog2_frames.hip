@@ -67,7 +67,6 @@ struct Mog2FramesArgs {
 // (cvt_gray's integer, one pass of the workgroup), and the kernel proceeds as the one-channel
 // kernel on that tile: no grey image ever exists in HBM.  CS = 0: frames arrive with C channels.
 // NT: frames staged per launch (kMaxT, or 1 for the per-frame call of a converting pipeline).
-constexpr int kGrayRowD = 20;   // dwords per grey tile row: 66 px + the 12-byte window's reach
 // MB: the 3x3 blur on the matrix pipe.  The launch is bound by vector-instruction issue and a third
 // of those instructions were the blur (27 v_dot4 + 6 multiply-adds per pixel and frame) while the
 // matrix pipe sat idle -- the two issue side by side.  The blur of a whole tile row is the product
@@ -203,26 +202,9 @@ __global__ __launch_bounds__(256, (C <= 3 && CS != 4) ? GOF_FRAMES_WAVES : 1) vo
     // model loads above stay in flight across it: __syncthreads() would wait for them, and a
     // settled wave would then sit out the second round trip of a neighbour that fetches five modes).
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    if (CS) {
-        // step 0 on the staged tiles: every pixel of every staged row of every frame once --
-        // (B * g0 + G * g1 + R * g2 + 2^13) >> 14, gray_kernel's statement -- into the grey tile
-        const int npx = ((x0 + TW + 1) < W ? (x0 + TW + 1) : W) - ft.sx0;   // staged pixels per row (<= 66)
-        const uint8_t *cb = (const uint8_t *)ctiles + ft.mis0;
-        uint8_t *gb = (uint8_t *)tiles;
-        // a wave takes every fourth staged row (all frames), a lane pixel `lane` of it and, for the
-        // first lanes, pixel 64 + lane: no index arithmetic beyond two running offsets
-        for (int rr = wave; rr < NT * (TH + 2); rr += 4) {
-            const uint8_t *crow = cb + (size_t)rr * Tiles::ROWD * 4;
-            uint8_t *grow = gb + (size_t)rr * ROWD * 4;
-#pragma unroll
-            for (int half = 0; half < 2; half++) {
-                const int px = lane + 64 * half;
-                if (px < npx) {
-                    const uint8_t *q = crow + px * CS;
-                    grow[px] = (uint8_t)((q[0] * a.g0 + q[1] * a.g1 + q[2] * a.g2 + (1 << 13)) >> 14);
-                }
-            }
-        }
+    if constexpr (CS != 0) {
+        // step 0 on the staged tiles, into the grey tile (gof_mog2_dev.h)
+        gray_tiles_from_staged<CS, NT>(ctiles, tiles, ft, x0, W, wave, lane, a.g0, a.g1, a.g2);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
 
@@ -567,10 +549,7 @@ hipError_t mog2_frames_launch(const uint8_t *frame, uint8_t *mask, const Mog2Sta
     a.modes = st.modes;
     a.np = st.np;
     a.frame_stride = (size_t)n_img * h * w * (src_c ? src_c : c);
-    const int B2Y = 1868, G2Y = 9617, R2Y = 4899;   // (cvt_gray's weights, gof_kernels.hip)
-    a.g0 = src_rgb ? R2Y : B2Y;
-    a.g1 = G2Y;
-    a.g2 = src_rgb ? B2Y : R2Y;
+    gray_weights(src_rgb, a.g0, a.g1, a.g2);
     a.btab = nullptr;
     a.cinit = 0;
     a.mask_stride = (size_t)n_img * h * w;

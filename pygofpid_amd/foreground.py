@@ -88,6 +88,7 @@ class ForegroundPipeline:
         _lib.check(lib.gof_pipeline_create(self._ctx.handle, C.byref(d), C.byref(self._h)))
         del keep  # the library copied the structuring elements
         self.model_c = 1 if convert else self.c     # channels the detector (and its model) work on
+        self.detector = detector
         if convert:
             _lib.check(lib.gof_pipeline_set_convert(self._h, self.c, int(convert == 'RGB2GRAY')))
 

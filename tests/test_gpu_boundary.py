@@ -319,3 +319,42 @@ def test_convert_and_box_blur_fused_into_the_detector(oracle, shape, cin):
         assert np.array_equal(got[i], ref.apply(cf[1 + i]))
     tot, det = pipe.algorithmic_bytes(1.0, 8)
     assert tot - det == 8 * 2 * h * w
+
+
+@pytest.mark.parametrize("detector", ["FD", "KNN"])
+@pytest.mark.parametrize("shape,cin,order", [((60, 88), 3, "BGR2GRAY"), ((61, 87), 3, "RGB2GRAY"), ((40, 130), 4, "RGB2GRAY"),
+                                             ((33, 70), 4, "BGR2GRAY"), ((270, 480), 3, "BGR2GRAY")])
+def test_convert_fused_into_fd_and_knn(oracle, detector, shape, cin, order):
+    """Step 0 inside the frame-differencing and the KNN kernels as well (colour rows staged, grey tile
+    built in LDS): masks equal the oracle's on oracle-converted frames, one frame and eight frames per
+    call, both channel orders, 3 and 4 source channels; geometries the staged front end does not take
+    (odd widths, 4-channel frames whose grey rows are not dword multiples) go through gray_kernel and give
+    the same masks.  The byte model counts no separate grey pass when the frames are aligned."""
+    from pygofpid_amd.foreground import ForegroundPipeline
+    h, w = shape
+    clip = Clip(h, w, 3, seed=13, n_objects=3)
+    rng = np.random.default_rng(4)
+
+    def frame(t):
+        f = clip.frame(t)
+        return f if cin == 3 else np.concatenate([f, rng.integers(0, 256, (h, w, 1), dtype=np.uint8)], axis=2)
+
+    frames = [frame(t) for t in range(18)]
+    grays = [oracle.cvt_gray(np.ascontiguousarray(f[:, :, :3]), rgb_order=(order == "RGB2GRAY")) for f in frames]
+    for blur, okw in (((3, 3, 4.0), dict(blur_k=3)), (("box", 3, 3), dict(blur_k=-3))):
+        pipe = ForegroundPipeline((h, w, cin), convert=order, blur=blur, detector=detector)
+        ref = oracle.Pipeline(h, w, 1, detector=detector, **okw)
+        assert np.array_equal(pipe.apply(frames[0]), ref.apply(grays[0]))
+        got = pipe.apply_many(np.stack(frames[1:9]))
+        for i in range(8):
+            assert np.array_equal(got[i], ref.apply(grays[1 + i])), (blur, i)
+        assert np.array_equal(pipe.apply(frames[9]), ref.apply(grays[9]))
+        got = pipe.apply_many(np.stack(frames[10:18]))
+        for i in range(8):
+            assert np.array_equal(got[i], ref.apply(grays[10 + i])), (blur, i)
+        if detector == "KNN":
+            a, b = pipe.knn_state(), ref.export()
+            assert all(np.array_equal(a[k], b[k]) for k in ("samples", "state"))
+        tot, det = pipe.algorithmic_bytes(1.0, 8)
+        if (w * cin) % 4 == 0 and (h * w * cin) % 4 == 0 and w % 4 == 0 and detector == "FD":
+            assert tot - det == 8 * 2 * h * w        # beyond the detector: the one morphology launch only
