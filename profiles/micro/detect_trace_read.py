@@ -10,7 +10,8 @@ d = sys.argv[1]
 ev = []
 for p in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(p)):
-        ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].split("<")[0].split("::")[-1]))
+        name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")
+        ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name.split("(")[0].split("<")[0].split("::")[-1]))
 for p in glob.glob(d + "/**/*memory_copy_trace.csv", recursive=True):
     for r in csv.DictReader(open(p)):
         s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
