@@ -1709,8 +1709,11 @@ int gof_pipeline_apply_host(gof_pipeline *p, const uint8_t *frames, uint8_t *mas
 // One host batch into a slot: upload on the copy stream (from pageable memory this call blocks
 // until the frames have left the caller's buffers -- while the context's stream runs the kernels
 // of the batch submitted before), then steps 1-3 and the blob extraction enqueued behind it.
+// inline_copy: the synchronous entry points -- nothing to overlap with, so the upload goes on the context's own
+// stream and the kernels follow it without the copy stream's event (no cross-queue dependency to resolve before
+// the first kernel starts).
 static int submit_host_blobs(gof_pipeline *p, const uint8_t *const *frames, const uint8_t *packed, int n_frames,
-                             gof_blobs *b, double min_area, int slot)
+                             gof_blobs *b, double min_area, int slot, bool inline_copy = false)
 {
     if (!p || !b || (!frames && !packed))
         return fail(GOF_EINVAL, "NULL argument");
@@ -1747,15 +1750,18 @@ static int submit_host_blobs(gof_pipeline *p, const uint8_t *const *frames, cons
     int rc;
     if ((rc = in.reserve((size_t)n_frames * per * cin)) || (rc = out.reserve((size_t)n_frames * per)))
         return rc;
+    hipStream_t up = inline_copy ? s : p->copy_stream;
     if (packed) {
-        GOF_HIP(hipMemcpyAsync(in.p, packed, (size_t)n_frames * per * cin, hipMemcpyHostToDevice, p->copy_stream));
+        GOF_HIP(hipMemcpyAsync(in.p, packed, (size_t)n_frames * per * cin, hipMemcpyHostToDevice, up));
     } else {
         for (int i = 0; i < n_frames; i++)
             GOF_HIP(hipMemcpyAsync((uint8_t *)in.p + (size_t)i * per * cin, frames[i], per * cin,
-                                   hipMemcpyHostToDevice, p->copy_stream));
+                                   hipMemcpyHostToDevice, up));
     }
-    GOF_HIP(hipEventRecord(p->ev_up[slot], p->copy_stream));
-    GOF_HIP(hipStreamWaitEvent(s, p->ev_up[slot], 0));
+    if (!inline_copy) {
+        GOF_HIP(hipEventRecord(p->ev_up[slot], p->copy_stream));
+        GOF_HIP(hipStreamWaitEvent(s, p->ev_up[slot], 0));
+    }
     if ((rc = gof_pipeline_apply_dev_many(p, in.p, out.p, n_frames, nullptr)))
         return rc;
     if ((rc = gof_blobs_extract_dev(b, out.p, n_frames * p->d.streams, min_area, nullptr)))
@@ -1792,14 +1798,16 @@ int gof_pipeline_apply_host_blobs(gof_pipeline *p, const uint8_t *frames, int n_
 {
     if (!frames)
         return fail(GOF_EINVAL, "NULL argument");
-    int rc = submit_host_blobs(p, nullptr, frames, n_frames, b, min_area, 0);
+    int rc = submit_host_blobs(p, nullptr, frames, n_frames, b, min_area, 0, true);
     return rc ? rc : gof_pipeline_wait_slot(p, 0);
 }
 
 int gof_pipeline_apply_host_blobs_ptrs(gof_pipeline *p, const uint8_t *const *frames, int n_frames,
                                        gof_blobs *b, double min_area)
 {
-    int rc = gof_pipeline_submit_host_blobs_ptrs(p, frames, n_frames, b, min_area, 0);
+    if (!frames)
+        return fail(GOF_EINVAL, "NULL argument");
+    int rc = submit_host_blobs(p, frames, nullptr, n_frames, b, min_area, 0, true);
     return rc ? rc : gof_pipeline_wait_slot(p, 0);
 }
 
