@@ -198,6 +198,9 @@ class GOFPID():
         thread runs the host steps on the records of batch k.  Any number of frames; memory is
         bounded by two batches.  All frames are validated before the first one is consumed.
         Attributes (`blobs_`, `tracked_blobs_`, `foreground_mask_`) are those of the last frame.
+        If a device call fails part-way (RuntimeError / MemoryError), the background model has taken the
+        frames of the batches submitted so far (up to 16 beyond the last frame whose host steps ran):
+        do not feed those frames again -- continue with the frames that follow, or initialize() anew.
         """
         frames = [np.asarray(f) for f in frames]
         shape = self.input_shape_ or (frames[0].shape if frames else None)

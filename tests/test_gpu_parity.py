@@ -666,6 +666,36 @@ def test_c_abi_error_codes():
     assert lib.gof_morph_dev(ctx.handle, 0, t.data_ptr(), t.data_ptr(), 1, 8, 8, None, 3, 3,
                              None) == _lib.EINVAL
     assert lib.gof_strerror(_lib.EHIP) == b"HIP runtime error"
+    # round 3: KNN and the asynchronous slots
+    k = C.c_void_p()
+    assert lib.gof_knn_create(ctx.handle, 1, 8, 8, 2, None, C.byref(k)) == _lib.EINVAL and not k
+    kp = _lib.KnnParams()
+    lib.gof_knn_default_params(C.byref(kp))
+    kp.nsamples = 17
+    assert lib.gof_knn_create(ctx.handle, 1, 8, 8, 3, C.byref(kp), C.byref(k)) == _lib.EINVAL and not k
+    assert b"KNN" in lib.gof_last_error()
+    assert lib.gof_knn_create(ctx.handle, 1, 8, 8, 3, None, C.byref(k)) == _lib.OK and k
+    m8 = np.zeros((8, 8), np.uint8)
+    assert lib.gof_knn_apply_host(k, None, p8(m8)) == _lib.EINVAL
+    assert lib.gof_knn_apply_dev(k, None, None, None) == _lib.EINVAL
+    assert lib.gof_knn_export(k, None, None) == _lib.EINVAL
+    assert lib.gof_knn_apply_host(k, p8(buf), p8(m8)) == _lib.OK and lib.gof_knn_nframes(k) == 1
+    lib.gof_knn_destroy(k)
+    assert lib.gof_pipeline_knn(pipe._h) is None            # a MOG2 pipeline has no KNN model
+    from pygofpid_amd.blobs import BlobExtractor
+    ex = BlobExtractor(1, 8, 8, ctx=pipe._ctx)
+    ptrs = (C.c_void_p * 1)(buf.ctypes.data)
+    assert lib.gof_pipeline_submit_host_blobs_ptrs(pipe._h, ptrs, 1, ex.handle, 100.0, 2) == _lib.EINVAL   # slot
+    assert lib.gof_pipeline_submit_host_blobs_ptrs(pipe._h, None, 1, ex.handle, 100.0, 0) == _lib.EINVAL
+    assert lib.gof_pipeline_submit_host_blobs_ptrs(pipe._h, ptrs, 2, ex.handle, 100.0, 0) == _lib.EINVAL   # scratch of 1 image
+    null = (C.c_void_p * 1)(None)
+    assert lib.gof_pipeline_submit_host_blobs_ptrs(pipe._h, null, 1, ex.handle, 100.0, 0) == _lib.EINVAL
+    assert lib.gof_pipeline_wait_slot(pipe._h, 3) == _lib.EINVAL
+    assert lib.gof_pipeline_wait_slot(pipe._h, 1) == _lib.OK                    # nothing in flight there
+    assert lib.gof_pipeline_fetch_masks_slot(pipe._h, p8(m8), 1, 1) == _lib.EINVAL   # no masks of slot 1 on the device
+    assert lib.gof_pipeline_submit_host_blobs_ptrs(pipe._h, ptrs, 1, ex.handle, 100.0, 0) == _lib.OK
+    assert lib.gof_pipeline_wait_slot(pipe._h, 0) == _lib.OK
+    assert lib.gof_pipeline_fetch_masks_slot(pipe._h, p8(m8), 1, 0) == _lib.OK
 
 
 # ---- KNN (cv.createBackgroundSubtractorKNN, reference pipeline.py:233-234) ------------------
