@@ -23,7 +23,7 @@ def child():
     import bench
     from pygofpid_amd import _lib
     from pygofpid_amd.foreground import ForegroundPipeline
-    S, T, h, w = 8, 8, 1080, 1920
+    S, T, h, w = 8, int(os.environ.get("FRAMES", "8")), 1080, 1920
     pool = int(os.environ.get("POOL", "256"))
     dev = torch.device("cuda", 0)
     if os.environ.get("NOISE"):
