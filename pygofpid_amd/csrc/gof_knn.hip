@@ -59,42 +59,76 @@ struct KnnSample {
 };
 
 template <int C>
+__device__ __forceinline__ KnnSample<C> knn_unpack(uint32_t w0, uint32_t w1)
+{
+    KnnSample<C> r;
+#pragma unroll
+    for (int c = 0; c < C; c++)
+        r.v[c] = (float)((w0 >> (8 * (c & 3))) & 255u);
+    r.flag = C <= 3 ? (w0 >> 24) != 0 : (w1 & 255u) != 0;
+    return r;
+}
+
+template <int C>
 __device__ __forceinline__ KnnSample<C> knn_load(const uint32_t *samples, size_t np, int s, size_t pix)
 {
     constexpr int WS = C <= 3 ? 1 : 2;
-    KnnSample<C> r;
     const uint32_t w0 = samples[(size_t)s * WS * np + pix];
-    if (C <= 3) {
-#pragma unroll
-        for (int c = 0; c < C; c++)
-            r.v[c] = (float)((w0 >> (8 * c)) & 255u);
-        r.flag = (w0 >> 24) != 0;
-    } else {
-        const uint32_t w1 = samples[((size_t)s * WS + 1) * np + pix];
-#pragma unroll
-        for (int c = 0; c < C; c++)
-            r.v[c] = (float)((w0 >> (8 * (c & 3))) & 255u);
-        r.flag = (w1 & 255u) != 0;
-    }
-    return r;
+    const uint32_t w1 = C <= 3 ? 0u : samples[((size_t)s * WS + 1) * np + pix];
+    return knn_unpack<C>(w0, w1);
 }
+
+// What a pixel's frame needs whatever the pixel looks like: its bookkeeping words and the first two sample
+// planes (no pixel can have its kNN >= 2 flagged neighbours before both are examined).  Requested at the
+// kernel's start, so that the round trip lies under the frame staging / blur instead of behind it.
+template <int C>
+struct KnnPrefetch {
+    uint32_t nx, ix, w[2][C <= 3 ? 1 : 2];
+    bool two;   // wave-uniform: planes 0 and 1 are here
+};
+
+template <int C>
+__device__ __forceinline__ KnnPrefetch<C> knn_prefetch(const KnnArgs &a, size_t pix)
+{
+    constexpr int WS = C <= 3 ? 1 : 2;
+    KnnPrefetch<C> p;
+    p.nx = a.next[pix];
+    p.ix = a.index[pix];
+    p.two = a.knn >= 2 && a.nN >= 1;   // (3 nN >= 3 planes)
+#pragma unroll
+    for (int s = 0; s < 2; s++)
+#pragma unroll
+        for (int q = 0; q < WS; q++)
+            p.w[s][q] = p.two ? a.samples[((size_t)s * WS + q) * a.np + pix] : 0u;
+    return p;
+}
+
+#ifndef GOF_KNN_SCAN
+#define GOF_KNN_SCAN 7
+#endif
+constexpr int kScan = GOF_KNN_SCAN;   // planes requested together once a wave scans beyond the first two
 
 // One pixel of cv2's KNNInvoker: check (background / shadow / foreground), refresh, new slots.
 // data / dbytes: the pixel's channels as floats / packed bytes; pix: its index in the planes;
 // valid == false: a lane that shadows a pixel (all of its stores are masked).
-template <int C>
-__device__ __forceinline__ void knn_pixel(const KnnArgs &a, size_t pix, bool valid, const float (&data)[C], uint32_t dbytes)
+// NS: the number of sample planes when it is known at compile time (21 = cv2's 3 x 7, and kNN >= 2: the launcher
+// checks), else 0.  With NS known the planes a wave has read stay in registers (NS dwords per pixel), and the
+// shadow loop -- which only ever runs in a wave that has read them all: a pixel that is not background has
+// been through every plane -- reads nothing again.
+template <int C, int NS = 0>
+__device__ __forceinline__ void knn_pixel(const KnnArgs &a, size_t pix, bool valid, const float (&data)[C], uint32_t dbytes,
+                                          const KnnPrefetch<C> &pre)
 {
     constexpr int WS = C <= 3 ? 1 : 2;
-    const int ns = 3 * a.nN;
+    const int ns = NS ? NS : 3 * a.nN;
+    uint32_t kept[NS ? NS : 1][WS];   // NS != 0: the planes read so far
+
+    const uint32_t nx = pre.nx, ix = pre.ix;
 
     // ---- _cvCheckPixelBackgroundNP, first loop: neighbours within Tb, flagged ones among them
     int Pbf = 0, Pb = 0;
     bool bg = false;
-    for (int s = 0; s < ns; s++) {
-        if (__builtin_amdgcn_ballot_w64(!bg) == 0)
-            break;   // every pixel of the wave has its kNN flagged neighbours: cv2's `return 1`
-        const KnnSample<C> m = knn_load<C>(a.samples, a.np, s, pix);
+    auto examine = [&](const KnnSample<C> &m) {
         float dist2;
         if (C == 3) {
             const float d0 = m.v[0] - data[0], d1 = m.v[1] - data[1], d2 = m.v[2] - data[2];
@@ -115,6 +149,61 @@ __device__ __forceinline__ void knn_pixel(const KnnArgs &a, size_t pix, bool val
                     bg = true;
             }
         }
+    };
+    int s = 0;
+    if (NS || pre.two) {
+        examine(knn_unpack<C>(pre.w[0][0], pre.w[0][WS - 1]));
+        examine(knn_unpack<C>(pre.w[1][0], pre.w[1][WS - 1]));
+        s = 2;
+    }
+    if constexpr (NS != 0) {
+#pragma unroll
+        for (int q = 0; q < WS; q++) {
+            kept[0][q] = pre.w[0][q];
+            kept[1][q] = pre.w[1][q];
+        }
+        // the same groups, with compile-time plane numbers: every plane lands in its own registers
+        bool go = true;
+#pragma unroll
+        for (int g = 2; g < NS; g += kScan) {
+            go = go && __builtin_amdgcn_ballot_w64(!bg) != 0;
+            if (go) {
+#pragma unroll
+                for (int j = 0; j < kScan; j++)
+                    if (g + j < NS) {
+#pragma unroll
+                        for (int q = 0; q < WS; q++)
+                            kept[g + j][q] = a.samples[((size_t)(g + j) * WS + q) * a.np + pix];
+                    }
+#pragma unroll
+                for (int j = 0; j < kScan; j++)
+                    if (g + j < NS && (j == 0 || __builtin_amdgcn_ballot_w64(!bg) != 0))
+                        examine(knn_unpack<C>(kept[g + j][0], kept[g + j][WS - 1]));
+            }
+        }
+        s = ns;
+    }
+    // A wave that is still looking after those reads on in groups of kScan planes requested together
+    // (examined in order, with the exit test between them: what a group fetched in vain is at most
+    // kScan - 1 planes, and only waves that hold a pixel off the settled background get here)
+    while (s < ns) {
+        if (__builtin_amdgcn_ballot_w64(!bg) == 0)
+            break;   // every pixel of the wave has its kNN flagged neighbours: cv2's `return 1`
+        uint32_t w[kScan][WS];
+#pragma unroll
+        for (int j = 0; j < kScan; j++) {
+            const int sj = s + j < ns ? s + j : ns - 1;
+#pragma unroll
+            for (int q = 0; q < WS; q++)
+                w[j][q] = a.samples[((size_t)sj * WS + q) * a.np + pix];
+        }
+#pragma unroll
+        for (int j = 0; j < kScan; j++) {
+            if (s + j >= ns || (j > 0 && __builtin_amdgcn_ballot_w64(!bg) == 0))
+                break;
+            examine(knn_unpack<C>(w[j][0], w[j][WS - 1]));
+        }
+        s += kScan;
     }
     const bool include = bg || Pbf >= a.knn;
 
@@ -124,10 +213,7 @@ __device__ __forceinline__ void knn_pixel(const KnnArgs &a, size_t pix, bool val
     if (a.detect_shadows && __builtin_amdgcn_ballot_w64(!bg) != 0) {
         bool done = bg;
         int Ps = 0;
-        for (int s = 0; s < ns; s++) {
-            if (__builtin_amdgcn_ballot_w64(!done) == 0)
-                break;
-            const KnnSample<C> m = knn_load<C>(a.samples, a.np, s, pix);
+        auto shadow = [&](const KnnSample<C> &m) {
             if (!done && m.flag) {
                 float num = 0.f, den = 0.f;
 #pragma unroll
@@ -154,12 +240,39 @@ __device__ __forceinline__ void knn_pixel(const KnnArgs &a, size_t pix, bool val
                     }
                 }
             }
+        };
+        if constexpr (NS != 0) {
+            // (some pixel of the wave is not background: the wave has been through all NS planes above)
+            bool go = true;
+#pragma unroll
+            for (int s2 = 0; s2 < NS; s2++) {
+                go = go && __builtin_amdgcn_ballot_w64(!done) != 0;
+                if (go)
+                    shadow(knn_unpack<C>(kept[s2][0], kept[s2][WS - 1]));
+            }
+        }
+        for (int s2 = NS ? ns : 0; s2 < ns; s2 += kScan) {
+            if (__builtin_amdgcn_ballot_w64(!done) == 0)
+                break;
+            uint32_t w[kScan][WS];
+#pragma unroll
+            for (int j = 0; j < kScan; j++) {
+                const int sj = s2 + j < ns ? s2 + j : ns - 1;
+#pragma unroll
+                for (int q = 0; q < WS; q++)
+                    w[j][q] = a.samples[((size_t)sj * WS + q) * a.np + pix];
+            }
+#pragma unroll
+            for (int j = 0; j < kScan; j++) {
+                if (s2 + j >= ns || (j > 0 && __builtin_amdgcn_ballot_w64(!done) == 0))
+                    break;
+                shadow(knn_unpack<C>(w[j][0], w[j][WS - 1]));
+            }
         }
     }
 
     // ---- _cvUpdatePixelBackgroundNP: long <- the mid set's oldest, mid <- the short set's oldest,
     //      short <- this pixel (offsets taken before any of the three); new slots at a cycle's end
-    const uint32_t nx = a.next[pix], ix = a.index[pix];
     uint32_t nS = nx & 255u, nM = (nx >> 8) & 255u, nL = (nx >> 16) & 255u;
     uint32_t iS = ix & 255u, iM = (ix >> 8) & 255u, iL = (ix >> 16) & 255u;
     const uint32_t img_pix = (uint32_t)(pix % a.hw);
@@ -203,12 +316,13 @@ __device__ __forceinline__ void knn_pixel(const KnnArgs &a, size_t pix, bool val
     a.mask[pix] = result == 0 ? (uint8_t)255 : (result == 1 ? (uint8_t)0 : (uint8_t)a.shadow_value);
 }
 
-template <int C>
+template <int C, int NS = 0>
 __global__ __launch_bounds__(256) void knn_kernel(const KnnArgs a)
 {
     const size_t pix0 = (size_t)blockIdx.x * 256 + threadIdx.x;
     const bool valid = pix0 < a.n;
     const size_t pix = valid ? pix0 : a.n - 1;   // lanes past the end shadow the last pixel; stores masked
+    const KnnPrefetch<C> pre = knn_prefetch<C>(a, pix);
     const uint8_t *px = a.frame + pix * C;
     uint32_t dbytes = 0;
     float data[C];
@@ -218,14 +332,14 @@ __global__ __launch_bounds__(256) void knn_kernel(const KnnArgs a)
         dbytes |= b << (8 * (c & 3));
         data[c] = (float)b;
     }
-    knn_pixel<C>(a, pix, valid, data, dbytes);
+    knn_pixel<C, NS>(a, pix, valid, data, dbytes, pre);
 }
 
 // GaussianBlur / cv.blur 3x3 + KNN in one kernel [REF pipeline.py:463-470]: the staging and tap-pattern
 // front end of the MOG2 kernels (64 x 4 px tiles, one wave per row, rows staged raw, the blur as dot
 // products against per-lane tap patterns), then knn_pixel on the blurred pixel: the blurred frame never
 // exists in memory.  Aligned frames only (fd_frames_supported); anything else runs blur_kernel + knn_kernel.
-template <int C>
+template <int C, int NS = 0>
 __global__ __launch_bounds__(256) void knn_blur3_kernel(const KnnArgs a)
 {
     typedef FrameTiles<C, 1> Tiles;
@@ -240,6 +354,9 @@ __global__ __launch_bounds__(256) void knn_blur3_kernel(const KnnArgs a)
     uint32_t raw[1][2][Tiles::NDW];
     ft.load(a.frame, 0, H, W, 1, img, x0, y0, wave, lane, raw);
     const bool valid = y < H && x < W;
+    // a lane outside the image shadows the first pixel of its tile's row inside it (stores masked)
+    const size_t pix = (size_t)img * H * W + (size_t)(y < H ? y : H - 1) * W + (x < W ? x : x0);
+    const KnnPrefetch<C> pre = knn_prefetch<C>(a, pix);   // (in flight across the staging barrier and the blur)
     TapPatterns<C> taps;
     {
         typedef const KnnArgs __attribute__((address_space(4))) *ArgsPtr0;
@@ -257,9 +374,7 @@ __global__ __launch_bounds__(256) void knn_blur3_kernel(const KnnArgs a)
         dbytes |= v[c] << (8 * (c & 3));
         data[c] = (float)v[c];
     }
-    // a lane outside the image shadows the first pixel of its tile's row inside it (stores masked)
-    const size_t pix = (size_t)img * H * W + (size_t)(y < H ? y : H - 1) * W + (x < W ? x : x0);
-    knn_pixel<C>(a, pix, valid, data, dbytes);
+    knn_pixel<C, NS>(a, pix, valid, data, dbytes, pre);
 }
 
 // the model as byte planes for export: samples[3 nN][C + 1][n], state[6][n]
@@ -322,6 +437,8 @@ hipError_t knn_apply(const uint8_t *frame, uint8_t *mask, const KnnState &st, in
     a.H = h;
     a.W = w;
     a.vky0 = a.vky1 = a.vround = 0;
+    // cv2's shape (3 x 7 samples, kNN >= 2): the planes a wave reads stay in registers (knn_pixel<C, 21>)
+    const bool cv2_shape = st.nN == 7 && st.knn >= 2;
     if (blur3) {
         // the 3x3 blur inside the kernel (the caller has checked knn_blur3_supported)
         if (!knn_blur3_supported(frame, n_img, h, w, c, *blur3))
@@ -331,21 +448,29 @@ hipError_t knn_apply(const uint8_t *frame, uint8_t *mask, const KnnState &st, in
         a.vround = blur3->vround;
         tap_table((uint32_t)blur3->kx[0] | ((uint32_t)blur3->kx[1] << 8) | ((uint32_t)blur3->kx[2] << 16), c, a.taps);
         const dim3 gb = grid3(w, h, n_img, TW, TH);
+#define GOF_LAUNCH_KNN(KERNEL, CC, GRID)                                                     \
+    do {                                                                                    \
+        if (cv2_shape)                                                                      \
+            hipLaunchKernelGGL((KERNEL<CC, 21>), GRID, dim3(256), 0, s, a);                  \
+        else                                                                                \
+            hipLaunchKernelGGL((KERNEL<CC, 0>), GRID, dim3(256), 0, s, a);                   \
+    } while (0)
         switch (c) {
-        case 1: hipLaunchKernelGGL(knn_blur3_kernel<1>, gb, dim3(256), 0, s, a); break;
-        case 3: hipLaunchKernelGGL(knn_blur3_kernel<3>, gb, dim3(256), 0, s, a); break;
-        case 4: hipLaunchKernelGGL(knn_blur3_kernel<4>, gb, dim3(256), 0, s, a); break;
+        case 1: GOF_LAUNCH_KNN(knn_blur3_kernel, 1, gb); break;
+        case 3: GOF_LAUNCH_KNN(knn_blur3_kernel, 3, gb); break;
+        case 4: GOF_LAUNCH_KNN(knn_blur3_kernel, 4, gb); break;
         default: return hipErrorInvalidValue;
         }
         return hipGetLastError();
     }
     const dim3 g((unsigned)((n + 255) / 256));
     switch (c) {
-    case 1: hipLaunchKernelGGL(knn_kernel<1>, g, dim3(256), 0, s, a); break;
-    case 3: hipLaunchKernelGGL(knn_kernel<3>, g, dim3(256), 0, s, a); break;
-    case 4: hipLaunchKernelGGL(knn_kernel<4>, g, dim3(256), 0, s, a); break;
+    case 1: GOF_LAUNCH_KNN(knn_kernel, 1, g); break;
+    case 3: GOF_LAUNCH_KNN(knn_kernel, 3, g); break;
+    case 4: GOF_LAUNCH_KNN(knn_kernel, 4, g); break;
     default: return hipErrorInvalidValue;
     }
+#undef GOF_LAUNCH_KNN
     return hipGetLastError();
 }
 

@@ -718,6 +718,23 @@ def test_knn_uniform_noise(cv, oracle, shape):
     _assert_knn_state_equal(gpu.export_state(), ref.export())
 
 
+@pytest.mark.parametrize("nsamples,knn,shadows", [(5, 1, True), (3, 2, True), (7, 1, False), (9, 3, True), (7, 2, False), (16, 2, True)])
+def test_knn_other_parameters(cv, oracle, nsamples, knn, shadows):
+    """Sample counts and kNN other than cv2's 3 x 7 / 2 take the kernels' run-time plane loop (the planes
+    are not kept in registers there), kNN = 1 the scan without the two planes requested up front: masks and
+    models equal the oracle on a clip with objects and shadows followed by uniform noise, colour and grey."""
+    for c in (3, 1):
+        h, w = 40, 72
+        clip = Clip(h, w, c, seed=21, n_objects=2)
+        gpu = cv.createBackgroundSubtractorKNN(detectShadows=shadows)
+        gpu._params.nsamples, gpu._params.knn = nsamples, knn
+        ref = oracle.KNN(nsamples=nsamples, knn=knn, detect_shadows=int(shadows))
+        frames = [clip.frame(t) for t in range(40)] + uniform_noise_frames((h, w, c) if c > 1 else (h, w), 12, seed=3)
+        for f in frames:
+            assert np.array_equal(gpu.apply(f), ref.apply(f))
+        _assert_knn_state_equal(gpu.export_state(), ref.export())
+
+
 @pytest.mark.parametrize("c", [1, 3])
 def test_knn_clip_masks_and_state(cv, oracle, c):
     """Static background + noise + moving objects + shadow patches through the learning-rate ramp
