@@ -216,28 +216,56 @@ class GOFPID():
         if getattr(self, '_uploader', None) is None:
             from concurrent.futures import ThreadPoolExecutor
             self._uploader = ThreadPoolExecutor(max_workers=1, thread_name_prefix='gofpid-upload')
+        import queue
+        import threading
         chunks = [frames[i:i + self._CHUNK] for i in range(0, len(frames), self._CHUNK)]
         submit = self._fused.submit_blobs_frames
-        fut = self._uploader.submit(submit, chunks[0], self._AREA_MIN, 0)
-        for k in range(len(chunks)):
-            slot = k & 1
-            fut.result()                              # batch k is on the device (or raised)
-            if k + 1 < len(chunks):
-                fut = self._uploader.submit(submit, chunks[k + 1], self._AREA_MIN, slot ^ 1)
-            masks = None
-            for i, res in enumerate(self._fused.wait_blobs(slot)):
-                self._gpu_blobs = res
-                self._mask = None
-                self._mask_on_device = True
-                self._mask_index = i
-                self._mask_slot = slot
-                if res is None:                       # device scratch overflow: this frame's mask, host path
-                    masks = self._fused.slot_masks(slot) if masks is None else masks
-                    self._mask = masks[i, 0]
-                self._find_blob()
-                self._track_blob()
-                self._post_filter()
-                out.append(self._maintain_alarm(self._detect_blob()))
+        # The helper thread walks the batches on its own: batch k + 2 goes up as soon as this thread has
+        # taken batch k's records out of its slot (free[slot]) -- not when it has finished their host steps --
+        # so the uploads follow each other on the link.  done: batch numbers (or the exception) in order.
+        free = [threading.Semaphore(1), threading.Semaphore(1)]
+        done = queue.SimpleQueue()
+        stop = threading.Event()
+
+        def upload_all():
+            try:
+                for k, chunk in enumerate(chunks):
+                    free[k & 1].acquire()
+                    if stop.is_set():
+                        return
+                    submit(chunk, self._AREA_MIN, k & 1)
+                    done.put(k)
+            except BaseException as e:          # handed to the calling thread
+                done.put(e)
+
+        fut = self._uploader.submit(upload_all)
+        try:
+            for k in range(len(chunks)):
+                slot = k & 1
+                got = done.get()                          # batch k is on the device (or the upload raised)
+                if isinstance(got, BaseException):
+                    raise got
+                results = self._fused.wait_blobs(slot)
+                # (a frame whose device scratch overflowed takes its mask and the host path: fetched before
+                # the slot is handed back)
+                masks = self._fused.slot_masks(slot) if any(r is None for r in results) else None
+                if k + 2 < len(chunks):
+                    free[slot].release()
+                for i, res in enumerate(results):
+                    self._gpu_blobs = res
+                    self._mask = masks[i, 0] if res is None else None
+                    self._mask_on_device = True
+                    self._mask_index = i
+                    self._mask_slot = slot
+                    self._find_blob()
+                    self._track_blob()
+                    self._post_filter()
+                    out.append(self._maintain_alarm(self._detect_blob()))
+        finally:
+            stop.set()
+            for sem in free:
+                sem.release()                             # (a helper waiting for a slot leaves)
+            fut.result()
         return out
 
     def _fusable(self):
