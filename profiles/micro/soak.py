@@ -40,5 +40,13 @@ for s in range(S if DET == "MOG2" else 0):
           and all(np.array_equal(st["mean"][:, ch, s * n:(s + 1) * n][live], ref["mean"][:, ch][live]) for ch in range(c)))
     print("stream %d final model state identical: %s" % (s, ok))
     bad += 0 if ok else 1
-print("soak %s: %d frames x %d streams, %d mismatches" % ("OK" if bad == 0 else "FAILED", N, S, bad))
+if DET == "KNN":
+    kst = gpu.knn_state()
+    for s in range(S):
+        ref = refs[s].export()
+        ok = (np.array_equal(kst["samples"][:, :, s * n:(s + 1) * n], ref["samples"])
+              and np.array_equal(kst["state"][:, s * n:(s + 1) * n], ref["state"]))
+        print("stream %d final sample model identical: %s" % (s, ok))
+        bad += 0 if ok else 1
+print("soak %s (%s): %d frames x %d streams, %d mismatches" % ("OK" if bad == 0 else "FAILED", DET, N, S, bad))
 sys.exit(1 if bad else 0)
