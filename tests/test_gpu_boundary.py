@@ -358,3 +358,59 @@ def test_convert_fused_into_fd_and_knn(oracle, detector, shape, cin, order):
         tot, det = pipe.algorithmic_bytes(1.0, 8)
         if (w * cin) % 4 == 0 and (h * w * cin) % 4 == 0 and w % 4 == 0 and detector == "FD":
             assert tot - det == 8 * 2 * h * w        # beyond the detector: the one morphology launch only
+
+
+@pytest.mark.parametrize("offset", [0, 1, 2, 3])
+@pytest.mark.parametrize("shape", [(33, 71, 3), (40, 64, 3), (17, 36, 4), (5, 5, 3)])
+def test_step0_on_device_buffers_of_any_alignment(oracle, offset, shape):
+    """gof_cvt_gray_dev (four pixels per thread on dwords when both buffers are dword-aligned, bytewise
+    otherwise, the last npix % 4 pixels bytewise) and the converting pipelines (step 0 inside the detector on
+    aligned colour frames, its own kernel otherwise) on frames that start at byte `offset` of an allocation and
+    end on its last byte: the oracle's grey image / masks, nothing written outside the output view."""
+    import torch
+    from pygofpid_amd import _lib
+    from pygofpid_amd.foreground import ForegroundPipeline
+    h, w, c = shape
+    rng = np.random.default_rng(offset + h)
+    lib, ctx, dev = _lib.load(), _lib.default_context(), torch.device("cuda", 0)
+    for n_img in (1, 3):
+        src = rng.integers(0, 256, (n_img, h, w, c), dtype=np.uint8)
+        sbuf = torch.empty(offset + src.size, dtype=torch.uint8, device=dev)
+        dbuf = torch.full((offset + n_img * h * w + 5,), 9, dtype=torch.uint8, device=dev)
+        sbuf[offset:].copy_(torch.from_numpy(src.reshape(-1)).to(dev))
+        for rgb in (0, 1):
+            _lib.check(lib.gof_cvt_gray_dev(ctx.handle, sbuf[offset:].data_ptr(), dbuf[offset:].data_ptr(), n_img, h, w, c,
+                                            rgb, None))
+            ctx.synchronize()
+            got = dbuf.cpu().numpy()
+            assert (got[:offset] == 9).all() and (got[offset + n_img * h * w:] == 9).all()
+            for i in range(n_img):
+                want = oracle.cvt_gray(np.ascontiguousarray(src[i, :, :, :3]), rgb_order=bool(rgb))
+                assert np.array_equal(got[offset + i * h * w:offset + (i + 1) * h * w].reshape(h, w), want)
+    # the converting pipelines on the same kind of views, 1 frame and 3 frames per call
+    T = 3
+    clip = Clip(h, w, 3, seed=offset, n_objects=2)
+
+    def frame(t):
+        f = clip.frame(t)
+        return f if c == 3 else np.concatenate([f, rng.integers(0, 256, (h, w, 1), dtype=np.uint8)], axis=2)
+    frames = np.stack([frame(t) for t in range(2 * T)])
+    for det in ("MOG2", "FD", "KNN"):
+        pipe = ForegroundPipeline((h, w, c), device=0, convert="BGR2GRAY", detector=det)
+        ref = oracle.Pipeline(h, w, 1, detector=det)
+        fbuf = torch.empty(offset + T * h * w * c, dtype=torch.uint8, device=dev)
+        mbuf = torch.full((offset + T * h * w,), 7, dtype=torch.uint8, device=dev)
+        fbuf[offset:].copy_(torch.from_numpy(frames[:T].reshape(-1)).to(dev))
+        pipe.apply_device(fbuf[offset:].data_ptr(), mbuf[offset:].data_ptr(), n_frames=T)
+        pipe.synchronize()
+        got = mbuf[offset:].cpu().numpy().reshape(T, h, w)
+        for t in range(T):
+            assert np.array_equal(got[t], ref.apply(oracle.cvt_gray(np.ascontiguousarray(frames[t][:, :, :3])))), (det, t)
+        assert (mbuf[:offset].cpu().numpy() == 7).all()
+        fbuf[offset:].copy_(torch.from_numpy(frames[T:].reshape(-1)).to(dev))
+        for t in range(T):
+            pipe.apply_device(fbuf[offset + t * h * w * c:].data_ptr(), mbuf[offset + t * h * w:].data_ptr())
+        pipe.synchronize()
+        got = mbuf[offset:].cpu().numpy().reshape(T, h, w)
+        for t in range(T):
+            assert np.array_equal(got[t], ref.apply(oracle.cvt_gray(np.ascontiguousarray(frames[T + t][:, :, :3])))), (det, T + t)
