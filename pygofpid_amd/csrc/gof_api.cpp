@@ -190,6 +190,7 @@ struct gof_blobs {
     int spill_image = -1;
     hipStream_t last = nullptr;
     bool pending = false;
+    bool dirty = false;             // a launch failed mid-extraction: the counters need clearing first
     int n_last = 0;
     DevBuf in;                      // masks of gof_blobs_extract_host
 };
@@ -1207,6 +1208,21 @@ int gof_blobs_create(gof_ctx *ctx, int n_images, int h, int w, int crack_capacit
         delete b;
         return fail(GOF_ENOMEM, "hipHostMalloc: %s", hipGetErrorString(e));
     }
+    // the finishing kernel writes the head of every image's block straight into that pinned buffer
+    // (no copy operation behind an extraction) and clears the counters behind itself (no memset in
+    // front of one): they start out zero here
+    void *mirror = nullptr;
+    e = hipHostGetDevicePointer(&mirror, b->host, 0);
+    if (e == hipSuccess)
+        e = hipMemset(B.counters, 0, n * gofk::kBlobCounters * sizeof(uint32_t));
+    if (e != hipSuccess) {
+        (void)hipFree(b->dev);
+        (void)hipHostFree(b->host);
+        delete b;
+        return fail(GOF_EHIP, "blob scratch set-up: %s", hipGetErrorString(e));
+    }
+    B.host_out = (uint32_t *)mirror;
+    B.host_words = b->head_words;
     *out = b;
     return GOF_OK;
 }
@@ -1239,9 +1255,16 @@ int gof_blobs_extract_dev(gof_blobs *b, const void *d_masks, int n_images, doubl
     hipStream_t s = pick(b->ctx, stream);
     gofk::BlobBuffers B = b->B;
     B.n_img = n_images;
-    GOF_HIP(gofk::blob_extract((const uint8_t *)d_masks, B, min_area, s));
-    GOF_HIP(hipMemcpy2DAsync(b->host, (size_t)b->head_words * 4, B.out, (size_t)B.out_words * 4,
-                             (size_t)b->head_words * 4, (size_t)n_images, hipMemcpyDeviceToHost, s));
+    if (b->dirty) {   // (an earlier launch failure left the counters half-used)
+        GOF_HIP(hipMemsetAsync(B.counters, 0, (size_t)b->n_img * gofk::kBlobCounters * sizeof(uint32_t), s));
+        b->dirty = false;
+    }
+    const hipError_t ee = gofk::blob_extract((const uint8_t *)d_masks, B, min_area, s);
+    if (ee != hipSuccess) {
+        b->dirty = true;
+        return fail(GOF_EHIP, "blob extraction launch: %s", hipGetErrorString(ee));
+    }
+    // (the records arrive in b->host with the finishing kernel's own stores: nothing to copy)
     b->last = s;
     b->pending = true;
     b->n_last = n_images;
@@ -1294,6 +1317,8 @@ extern "C" int gof_blobs_debug_counters(gof_blobs *b, int image, uint32_t *out16
         return rc ? rc : GOF_EINVAL;
     GOF_HIP(hipMemcpy(out16, b->B.counters + (size_t)image * gofk::kBlobCounters,
                       gofk::kBlobCounters * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 4; i++)   // (the live counters are cleared by the finishing kernel: its copies)
+        out16[i] = out16[gofk::kCntLast + i];
     return GOF_OK;
 }
 

@@ -602,8 +602,10 @@ __global__ __launch_bounds__(256) void blob_stats_kernel(BlobBuffers B)
 constexpr int FT = 1024;           // threads
 constexpr int kMaxBlobs = 4096;    // returned borders per image (more: kFlagBlobOverflow, the host takes the mask)
 
-__global__ __launch_bounds__(FT) void blob_finish_kernel(const uint8_t *__restrict__ mask, BlobBuffers B,
-                                                         double min_area)
+// (the body returns at several places, always for the whole workgroup; the kernel proper, below, adds
+// what has to happen whichever way it went)
+__device__ __forceinline__ void blob_finish_body(const uint8_t *__restrict__ mask, const BlobBuffers &B,
+                                                 double min_area)
 {
     const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t *cnts = B.counters + (size_t)img * kBlobCounters;
@@ -898,6 +900,36 @@ __global__ __launch_bounds__(FT) void blob_finish_kernel(const uint8_t *__restri
         cnts[4 + 7] = (uint32_t)wall_clock64();
 }
 
+__global__ __launch_bounds__(FT) void blob_finish_kernel(const uint8_t *__restrict__ mask, BlobBuffers B,
+                                                         double min_area)
+{
+    blob_finish_body(mask, B, min_area);
+    // Behind the body, whichever way it left: (1) the head of the output block -- header, records,
+    // points, as far as the mirror reaches -- goes to the host-visible mirror (plain stores over the
+    // link, visible to the host when the kernel has completed: no copy operation queued behind the
+    // extraction); (2) the counters are cleared for the next extraction (no memset in front of it),
+    // a copy kept for diagnostics.
+    const int img = blockIdx.x, tid = threadIdx.x;
+    uint32_t *cnts = B.counters + (size_t)img * kBlobCounters;
+    const uint32_t *out = B.out + (size_t)img * B.out_words;
+    __syncthreads();
+    if (B.host_out != nullptr) {
+        const BlobHeader *hdr = (const BlobHeader *)out;
+        unsigned long long words = kBlobHeaderWords;
+        if (hdr->flags == 0)
+            words += (unsigned long long)hdr->n_blobs * kBlobRecordWords + hdr->n_points;
+        if (words > B.host_words)
+            words = B.host_words;
+        uint32_t *dst = B.host_out + (size_t)img * B.host_words;
+        for (uint32_t i = tid; i < (uint32_t)words; i += FT)
+            dst[i] = out[i];
+    }
+    if (tid < 4) {
+        cnts[kCntLast + tid] = cnts[tid];
+        cnts[tid] = 0;
+    }
+}
+
 }  // namespace
 
 hipError_t blob_extract(const uint8_t *mask, const BlobBuffers &B, double min_area, hipStream_t s)
@@ -906,9 +938,6 @@ hipError_t blob_extract(const uint8_t *mask, const BlobBuffers &B, double min_ar
         (B.h + 3) / 4 > 65535 || B.cap < 16 || B.cap > (1u << 28) || (B.cap & 3u) ||
         B.out_words < kBlobHeaderWords || (size_t)B.h * B.w > (1u << 30))
         return hipErrorInvalidValue;
-    hipError_t e = hipMemsetAsync(B.counters, 0, (size_t)B.n_img * kBlobCounters * sizeof(uint32_t), s);
-    if (e != hipSuccess)
-        return e;
     const unsigned tiles_x = (unsigned)((B.w + TX - 1) / TX), tiles_y = (unsigned)((B.h + TY - 1) / TY);
     if (B.seg_cap < tiles_x * tiles_y)
         return hipErrorInvalidValue;

@@ -214,8 +214,10 @@ struct BlobRecord {            // == gof_blob_record (include/gofpid_hip.h)
     long long a00, a10, a01;
 };
 constexpr uint32_t kBlobHeaderWords = sizeof(BlobHeader) / 4, kBlobRecordWords = sizeof(BlobRecord) / 4;
-constexpr int kBlobCounters = 16;   // 0..3 counts / flags, 4.. phase stamps of the finishing kernel (100 MHz ticks)
-enum { kCntCracks = 0, kCntRoots = 1, kCntFlags = 2, kCntSegs = 3 };
+// 0..3 counts / flags (zero between extractions: the finishing kernel clears them behind itself), 4..11 phase
+// stamps of the finishing kernel (100 MHz ticks), 12..15 the counts / flags of the last extraction (diagnostics)
+constexpr int kBlobCounters = 16;
+enum { kCntCracks = 0, kCntRoots = 1, kCntFlags = 2, kCntSegs = 3, kCntLast = 12 };
 enum { kFlagCrackOverflow = 1, kFlagBlobOverflow = 2, kFlagPointOverflow = 4, kFlagInternal = 8 };
 
 struct BlobBuffers {           // device scratch for n_img masks of h x w; cap = crack slots per image
@@ -229,12 +231,18 @@ struct BlobBuffers {           // device scratch for n_img masks of h x w; cap =
     BlobAcc *acc;              // [n_img][cap / 4]
     uint32_t *segs;            // [n_img][seg_cap]  tiles (256 px x 16 rows) with foreground: ty << 16 | tx
     uint32_t seg_cap;          // >= ceil(h / 16) * ceil(w / 256)
-    uint32_t *counters;        // [n_img][kBlobCounters]
+    uint32_t *counters;        // [n_img][kBlobCounters]; all zero before an extraction (blob_extract's contract)
     uint32_t *out;             // [n_img][out_words]
+    // host-visible (pinned, device-mapped) mirror of the head of every image's output block, written by the
+    // finishing kernel itself: no copy operation behind the kernels.  NULL: no mirror.
+    uint32_t *host_out;        // [n_img][host_words]
+    uint32_t host_words;
 };
 
 // External contours (RETR_EXTERNAL, CHAIN_APPROX_NONE) of n_img masks with polygon area
 // >= min_area: records + ordered points into B.out, one block per image.  Enqueues only.
+// B.counters must be zero on entry (they are after a completed extraction; after a failed launch the
+// caller clears them).
 hipError_t blob_extract(const uint8_t *mask, const BlobBuffers &B, double min_area, hipStream_t s);
 
 // sum of modes[] (for m-bar); out is a device uint64 accumulator, zeroed by caller.
